@@ -1,0 +1,277 @@
+// Batched multi-scalar multiplication over fixed bases: out[p] = sum_i s[i][p] * P_i, p < batch.
+//
+// Replaces G1Jac.MultiExp / G2Jac.MultiExp (gnark-crypto ecc/bn254/multiexp*.go) as groth16.Prove
+// calls them - four G1 and one G2 MSM per proof over the proving key's bases
+// [UPSTREAM-RECALL, SURVEY.md §3.2 step 5].  The result is the affine group element, which is
+// canonical, so it equals gnark's bucket-method result bit for bit.
+//
+// MI355X-first design.  gnark runs Pippenger per proof because a CPU sees one
+// proof at a time.  Here a batch of proofs shares the bases, and the bases are fixed for the
+// lifetime of the circuit, so the work is organised the other way round:
+//   * pk_load expands every base into an HBM-resident table of all signed window multiples
+//     T[i][j][d-1] = d * 2^(c*j) * P_i, d = 1..2^(c-1), affine.  With c = 10 that is ~0.85 MB
+//     per G1 base - ~140 GB for the 166 k G1 bases of the Arbo-160 circuit - which is exactly what
+//     288 GB of HBM3E is for.  There are no buckets, no bucket reduction, no sorting.
+//   * one lane = one proof.  A wavefront walks a contiguous chunk of (base, window) pairs; at
+//     each step all 64 lanes need an entry of the SAME 2^(c-1)-entry table slice, selected by
+//     their own digit, and add it into a register-resident XYZZ accumulator with one mixed
+//     addition.  Scalars are read once, coalesced across lanes; the table slice is shared by
+//     every wave working on that chunk, so it streams from HBM once per batch.
+//   * a second tiny kernel sums the per-chunk partial accumulators of each proof.
+// Cost: ceil(255/c) mixed additions per (base, proof) and nothing else.  The bound is the vector
+// integer ALU (v_mad_u64_u32), not HBM; both fractions are reported by bench.py.
+//
+// Algorithmic bytes per launch: n * sizeof(affine) + batch * n * 32.
+#include "zkmi_internal.h"
+
+namespace zk {
+
+// ---- table construction ------------------------------------------------------------------------
+// One thread per base, windows in sequence.  Per window: D = 2^(c-1) running mixed additions into
+// XYZZ, then one Montgomery batch inversion over the D denominators (scratch is interleaved across
+// threads so lanes touch adjacent addresses), then 2^c * Q for the next window.
+template <class F>
+__global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restrict__ bases,
+                                                      uint32_t i0, uint32_t n, int c, int W,
+                                                      Affine<F>* __restrict__ table,
+                                                      F* __restrict__ scratch, uint32_t T) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = i0 + t;
+  if (t >= T || i >= n) return;
+  const uint32_t D = 1u << (c - 1);
+  F* szz = scratch + t;
+  F* szzz = scratch + (size_t)D * T + t;
+  F* spre = scratch + (size_t)2 * D * T + t;
+  Affine<F> Q = bases[i];
+  for (int j = 0; j < W; j++) {
+    Affine<F>* row = table + (((size_t)i * W + j) << (c - 1));
+    if (Q.is_inf()) {
+      for (uint32_t d = 0; d < D; d++) row[d] = Affine<F>::inf();
+      continue;
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    F pref = F::one();
+    for (uint32_t d = 0; d < D; d++) {
+      madd(acc, Q);
+      row[d].x = acc.x;
+      row[d].y = acc.y;
+      szz[(size_t)d * T] = acc.zz;
+      szzz[(size_t)d * T] = acc.zzz;
+      spre[(size_t)d * T] = pref;
+      pref = mul(pref, acc.zzz);
+    }
+    F inv = inverse(pref);
+    for (uint32_t d = D; d-- > 0;) {
+      F zzz = szzz[(size_t)d * T];
+      F izzz = mul(inv, spre[(size_t)d * T]);
+      inv = mul(inv, zzz);
+      F izz = sqr(mul(izzz, szz[(size_t)d * T]));
+      row[d].x = mul(row[d].x, izz);
+      row[d].y = mul(row[d].y, izzz);
+    }
+    if (j + 1 < W) Q = to_affine(dbl_affine(row[D - 1]));
+  }
+}
+
+// ---- accumulation --------------------------------------------------------------------------------
+// grid: x over proofs (Bp / blockDim.x), y over chunks of bases.  c, W uniform.
+template <class F>
+__global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restrict__ table,
+                                                      const Fr* __restrict__ scalars,
+                                                      const uint32_t* __restrict__ row_idx,
+                                                      size_t Bp, uint32_t n, uint32_t per_chunk,
+                                                      int c, int W, XYZZ<F>* __restrict__ partial) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y;
+  const uint32_t i0 = chunk * per_chunk;
+  uint32_t i1 = i0 + per_chunk;
+  if (i1 > n) i1 = n;
+  const uint32_t mask = (1u << c) - 1u;
+  const uint32_t half = 1u << (c - 1);
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t row = row_idx ? row_idx[i] : i;
+    Fr s = from_mont(scalars[(size_t)row * Bp + b]);
+    if (s.is_zero()) continue;
+    const Affine<F>* trow = table + (((size_t)i * W) << (c - 1));
+    uint32_t carry = 0;
+    for (int j = 0; j < W; j++) {
+      uint32_t d = (s.v[0] & mask) + carry;
+#pragma unroll
+      for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> c) | (s.v[l + 1] << (32 - c));
+      s.v[7] >>= c;
+      const bool negd = d > half;
+      carry = negd ? 1u : 0u;
+      const uint32_t mag = negd ? (mask + 1u - d) : d;
+      if (mag) {
+        Affine<F> p = trow[((size_t)j << (c - 1)) + (mag - 1)];
+        if (negd) p.y = neg(p.y);
+        madd(acc, p);
+      }
+    }
+  }
+  partial[(size_t)chunk * Bp + b] = acc;
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void msm_reduce(const XYZZ<F>* __restrict__ partial, size_t Bp,
+                                                 uint32_t chunks, XYZZ<F>* __restrict__ out) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  XYZZ<F> acc = partial[b];
+  for (uint32_t k = 1; k < chunks; k++) {
+    XYZZ<F> p = partial[(size_t)k * Bp + b];
+    padd(acc, p);
+  }
+  out[b] = acc;
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __restrict__ in,
+                                                            Affine<F>* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = to_affine(in[i]);
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int default_window(size_t n, int group) {
+  // keep the table under ~96 GB for G1 and ~48 GB for G2 (the Arbo-160 key then takes c = 10 / 9)
+  const double budget = group == 1 ? 96e9 : 48e9;
+  const double entry = group == 1 ? 64.0 : 128.0;
+  int best = 4;
+  for (int c = 4; c <= 12; c++) {
+    const int W = (255 + c - 1) / c;
+    const double bytes = (double)n * W * (double)(1u << (c - 1)) * entry;
+    if (bytes <= budget) best = c;
+  }
+  return best;
+}
+
+template <class F>
+static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c, int W,
+                      Affine<F>* table) {
+  const uint32_t D = 1u << (c - 1);
+  // slab of threads sized so the inversion scratch stays under ~2 GB
+  size_t per_thread = (size_t)3 * D * sizeof(F);
+  size_t T = (size_t)2e9 / per_thread;
+  if (T > n) T = n;
+  T = round_up(T, 64);
+  if (T > 65536) T = 65536;
+  void* scratch;
+  int rc = ensure_scratch(ctx, 7, per_thread * T, &scratch);
+  if (rc) return rc;
+  for (size_t i0 = 0; i0 < n; i0 += T) {
+    hipLaunchKernelGGL((msm_build_table<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
+                       bases_dev, (uint32_t)i0, (uint32_t)n, c, W, table, (F*)scratch,
+                       (uint32_t)T);
+  }
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, int c,
+                    zkmi_msm_bases** out) {
+  if (group != 1 && group != 2) {
+    ctx->err = "group must be 1 (G1) or 2 (G2)";
+    return ZKMI_ERR_ARG;
+  }
+  if (c == 0) c = default_window(n, group);
+  if (c < 2 || c > 16) {
+    ctx->err = "window_bits must be in [2,16]";
+    return ZKMI_ERR_ARG;
+  }
+  auto* b = new zkmi_msm_bases();
+  b->group = group;
+  b->n = n;
+  b->c = c;
+  b->n_windows = (255 + c - 1) / c;
+  const size_t entry = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
+  b->table_bytes = n * (size_t)b->n_windows * ((size_t)1 << (c - 1)) * entry;
+  if (n == 0) {
+    *out = b;
+    return ZKMI_OK;
+  }
+  hipError_t e = hipMalloc(&b->table, b->table_bytes);
+  if (e != hipSuccess) {
+    ctx->err = "hipMalloc of MSM window table failed (" + std::to_string(b->table_bytes) +
+               " bytes): " + hipGetErrorString(e);
+    delete b;
+    return ZKMI_ERR_OOM;
+  }
+  int rc = group == 1 ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, c, b->n_windows,
+                                       (G1Affine*)b->table)
+                      : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, c, b->n_windows,
+                                        (G2Affine*)b->table);
+  if (rc) {
+    hipFree(b->table);
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+
+template <class F>
+static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
+                    const uint32_t* row_idx, size_t Bp, XYZZ<F>* out) {
+  const size_t n = bases->n;
+  // enough chunks for ~4 waves per SIMD over the whole chip
+  size_t chunks = (size_t)262144 / Bp;
+  if (chunks < 1) chunks = 1;
+  if (chunks > n) chunks = n;
+  uint32_t per_chunk = (uint32_t)((n + chunks - 1) / chunks);
+  chunks = (n + per_chunk - 1) / per_chunk;
+  void* partial;
+  int rc = ensure_scratch(ctx, 6, chunks * Bp * sizeof(XYZZ<F>), &partial);
+  if (rc) return rc;
+  const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
+  hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx), 0,
+                     ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
+                     (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
+                     (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, out);
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+
+__global__ void fill_inf_g1(G1XYZZ* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = G1XYZZ::inf();
+}
+__global__ void fill_inf_g2(G2XYZZ* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = G2XYZZ::inf();
+}
+
+int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
+            size_t Bp, void* out_xyzz) {
+  if (bases->n == 0) {
+    if (bases->group == 1)
+      hipLaunchKernelGGL(fill_inf_g1, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
+                         (G1XYZZ*)out_xyzz, Bp);
+    else
+      hipLaunchKernelGGL(fill_inf_g2, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
+                         (G2XYZZ*)out_xyzz, Bp);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+  }
+  if (bases->group == 1) return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz);
+  return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz);
+}
+
+int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n) {
+  if (n == 0) return ZKMI_OK;
+  const unsigned g = (unsigned)((n + 63) / 64);
+  if (group == 1)
+    hipLaunchKernelGGL((xyzz_to_affine_kernel<Fq>), dim3(g), dim3(64), 0, ctx->stream,
+                       (const G1XYZZ*)in, (G1Affine*)out, n);
+  else
+    hipLaunchKernelGGL((xyzz_to_affine_kernel<Fq2>), dim3(g), dim3(64), 0, ctx->stream,
+                       (const G2XYZZ*)in, (G2Affine*)out, n);
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,124 @@
+// Internal declarations shared by the HIP translation units of libzkmi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/zkmi.h"
+#include "ec.h"
+
+namespace zk {
+
+// Device layout used everywhere on the hot path: "batch-inner".  A logical matrix of field
+// elements [row][proof] is stored with the proof index fastest, so that the 64 lanes of a
+// wavefront work on 64 different proofs at the same row: loads/stores are 2 KiB contiguous per
+// wave, and everything indexed by row (twiddles, constants, window-table slices, program words)
+// is wave-uniform and comes through the scalar unit.  Bp = batch rounded up to 64.
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct NttPlan {
+  int log_n = 0;
+  Fr* tw_fwd = nullptr;     // n/2 powers of w
+  Fr* tw_inv = nullptr;     // n/2 powers of w^-1
+  Fr* coset_fwd = nullptr;  // g^i, n
+  Fr* coset_inv = nullptr;  // g^-i / n, n
+  Fr n_inv;                 // 1/n
+  Fr den;                   // 1/(g^n - 1)
+};
+
+}  // namespace zk
+
+struct zkmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<zk::NttPlan> plans;
+  hipEvent_t ev[8] = {};
+  double timings[8] = {};
+  // scratch arena for the prove pipeline, grown on demand
+  zk::DevBuf scratch[8];
+};
+
+struct zkmi_msm_bases {
+  int group = 1;        // 1 = G1, 2 = G2
+  size_t n = 0;         // number of bases
+  int c = 0;            // window bits
+  int n_windows = 0;
+  void* table = nullptr;  // affine entries [(i * W + j) << (c-1) | (d-1)]
+  size_t table_bytes = 0;
+};
+
+struct zkmi_pk {
+  uint32_t log_n = 0, n_wires = 0, n_a = 0, n_b = 0, n_k = 0, n_z = 0;
+  uint32_t *a_wire = nullptr, *b_wire = nullptr, *k_wire = nullptr;  // device
+  zkmi_msm_bases *A = nullptr, *B1 = nullptr, *K = nullptr, *Z = nullptr, *B2 = nullptr;
+  zk::G1Affine alpha, beta1, delta1;
+  zk::G2Affine beta2, delta2;
+};
+
+struct zkmi_cs {
+  uint32_t n_wires = 0, n_public = 0, n_secret = 0, n_constraints = 0, n_slots = 0, n_ops = 0,
+           n_consts = 0;
+  uint32_t* program = nullptr;  // device
+  zk::Fr* consts = nullptr;     // device
+};
+
+namespace zk {
+
+// witness-program opcodes (frontend/api.py)
+enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC,
+       OP_ABC, OP_COPY, OP_DIV };
+
+#define ZK_HIP(call)                                                         \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(_e);          \
+      return ZKMI_ERR_HIP;                                                   \
+    }                                                                        \
+  } while (0)
+
+static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out);
+
+// layout conversion (proof-major <-> batch-inner), rows x batch elements of `elem_bytes`
+int transpose_in(zkmi_ctx* ctx, const void* src_pm, void* dst_bi, size_t rows, size_t batch,
+                 size_t Bp, size_t elem_bytes);
+int transpose_out(zkmi_ctx* ctx, const void* src_bi, void* dst_pm, size_t rows, size_t batch,
+                  size_t Bp, size_t elem_bytes);
+
+// ntt.hip
+int get_plan(zkmi_ctx* ctx, int log_n, NttPlan** out);
+// src -> dst (distinct buffers), batch-inner [n][Bp]; rows >= n_valid of src are read as zero
+int ntt_bi(zkmi_ctx* ctx, const NttPlan* plan, const Fr* src, Fr* dst, size_t Bp, bool inverse,
+           bool coset, size_t n_valid);
+// h = (a*b - c) * den, elementwise over n*Bp
+int pointwise_h(zkmi_ctx* ctx, const NttPlan* plan, const Fr* a, const Fr* b, const Fr* c, Fr* h,
+                size_t Bp);
+// full quotient: a,b,c batch-inner [n][Bp] (rows >= n_valid zero) -> h in `a_out`; t0,t1 scratch
+int compute_h_bi(zkmi_ctx* ctx, const NttPlan* plan, Fr* a, Fr* b, Fr* c, Fr* t0, size_t Bp,
+                 size_t n_valid, Fr** h_out);
+
+// msm.hip
+int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, int c,
+                    zkmi_msm_bases** out);
+// scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)
+// maps base i to its scalar row.  out_xyzz: Bp accumulators.
+int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
+            size_t Bp, void* out_xyzz);
+
+int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n);
+
+// solve.hip
+// slots [n_slots][Bp] with rows 0..n_inputs pre-filled; writes every wire row, a/b/c rows
+// [0, n_constraints) and status[Bp] (0 or ZKMI_ERR_UNSATISFIED)
+int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
+             size_t Bp);
+
+}  // namespace zk

@@ -1,0 +1,426 @@
+"""R1CS builder exposing the subset of gnark's ``frontend.API`` that the reference gadgets call.
+
+The reference's gadgets are Go functions over ``frontend.API`` (e.g.
+hash/native/bn254/poseidon/poseidon.go:154-232, tree/smt/*.go, elgamal/mul.go:86-161); the
+builder behind that interface lives in the third-party module gnark (go.mod:8, not in
+/root/reference).  This module restates the behaviour of gnark's ``frontend/cs/r1cs`` builder
+that those call sites rely on [UPSTREAM-RECALL, SURVEY.md §8a]:
+
+* a ``Variable`` is a linear expression over wires; wire 0 is the constant ONE;
+* Add/Sub/Neg and multiplication by a constant fold into the expression and cost nothing;
+* ``Mul`` of two non-constant expressions allocates one internal wire and one constraint;
+* ``IsZero`` = InvZero hint + 2 constraints; ``ToBinary(n)`` = NBits hint + n booleanity
+  constraints + 1 equality; ``Select``/``And``/``Or``/``Xor`` = 1 constraint (+1 per operand not
+  yet known to be boolean); ``Lookup2`` = 2 constraints; ``AssertIsEqual`` = 1 constraint.
+
+Besides the R1CS (L, R, O in CSR form plus the solve order), the builder records a
+straight-line *witness program* in SSA form: every API call appends the field operation that
+produces its value.  The GPU solver (csrc/solve.hip) runs that program with one lane per proof;
+the per-constraint evaluations a_k = <L_k,w>, b_k, c_k that Groth16's quotient needs are then
+simply the operand values of the constraint-producing instructions.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+# witness-program opcodes (decoded by csrc/solve.hip and by CompiledCircuit.run_program)
+OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC, OP_ABC, \
+    OP_COPY, OP_DIV = range(13)
+
+HINT_INVZERO, HINT_NBITS = 1, 2
+
+
+class Variable:
+    """Linear expression sum_i coef_i * wire_i (wire 0 = ONE) plus the SSA value that holds it."""
+    __slots__ = ("lc", "val")
+
+    def __init__(self, lc, val):
+        self.lc = lc      # dict wire -> coef (non-zero, reduced mod R)
+        self.val = val    # SSA value id
+
+    def is_const(self):
+        return all(w == 0 for w in self.lc)
+
+    def const_value(self):
+        return self.lc.get(0, 0)
+
+
+def _lc_add(a, b, sb=1):
+    out = dict(a)
+    for w, c in b.items():
+        v = (out.get(w, 0) + sb * c) % R
+        if v:
+            out[w] = v
+        else:
+            out.pop(w, None)
+    return out
+
+
+def _lc_scale(a, k):
+    k %= R
+    if k == 0:
+        return {}
+    return {w: c * k % R for w, c in a.items()}
+
+
+class CompileError(Exception):
+    pass
+
+
+class API:
+    """Mirror of the calls the reference gadgets make on gnark's frontend.API."""
+
+    def __init__(self):
+        self.n_wires = 1            # wire 0 = ONE
+        self.n_public = 1
+        self.n_secret = 0
+        self.constraints = []       # (L, R, O, solve_wire, (va, vb, vc))
+        self.instr = []             # (kind, index): 0 = R1C, 1 = hint
+        self.hints = []             # (kind, [input lc], [output wires])
+        self.ops = []               # SSA ops: (opcode, dst_val, a, b) ; see _emit
+        self.n_vals = 0
+        self.val_wire = {}          # SSA value id -> wire whose slot it lives in
+        self.consts = {}            # int -> const pool index
+        self.const_list = []
+        self.booleans = set()
+        self._inputs_open = True
+        self.input_names = []
+        self.val_one = self._new_val()
+        self.val_wire[self.val_one] = 0
+        self.val_zero = None
+        self.println_log = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _new_val(self):
+        v = self.n_vals
+        self.n_vals += 1
+        return v
+
+    def _cid(self, c):
+        c %= R
+        i = self.consts.get(c)
+        if i is None:
+            i = len(self.const_list)
+            self.consts[c] = i
+            self.const_list.append(c)
+        return i
+
+    def _emit(self, op, a=0, b=0, dst=None):
+        if dst is None:
+            dst = self._new_val()
+        self.ops.append((op, dst, a, b))
+        return dst
+
+    def _new_wire(self, val=None):
+        w = self.n_wires
+        self.n_wires += 1
+        if val is not None:
+            self.val_wire[val] = w
+        return w
+
+    def _input(self, name, public):
+        if not self._inputs_open:
+            raise CompileError("inputs must be declared before any constraint")
+        if public and self.n_secret:
+            raise CompileError("public inputs come first (gnark wire order)")
+        v = self._new_val()
+        w = self._new_wire(v)
+        if public:
+            self.n_public += 1
+        else:
+            self.n_secret += 1
+        self.input_names.append(name)
+        return Variable({w: 1}, v)
+
+    def public_input(self, name):
+        return self._input(name, True)
+
+    def secret_input(self, name):
+        return self._input(name, False)
+
+    def _const(self, c):
+        c %= R
+        if c == 1:
+            return Variable({0: 1}, self.val_one)
+        v = self._emit(OP_SETC, 0, self._cid(c))
+        return Variable({0: c} if c else {}, v)
+
+    def _v(self, x):
+        if isinstance(x, Variable):
+            return x
+        if isinstance(x, (int, np.integer)):
+            return self._const(int(x))
+        raise CompileError(f"unsupported operand {type(x)}")
+
+    @staticmethod
+    def _key(v):
+        return tuple(sorted(v.lc.items()))
+
+    def _add_r1c(self, L, R_, O, solve_wire=-1):
+        self._inputs_open = False
+        k = len(self.constraints)
+        self.constraints.append((L.lc, R_.lc, O.lc, solve_wire, (L.val, R_.val, O.val)))
+        self.instr.append((0, k))
+        self._emit(OP_ABC, R_.val, O.val, dst=L.val)   # (sa, sb, sc) = (dst, a, b)
+        return k
+
+    def _internal(self, val):
+        """Fresh internal wire whose value is SSA value `val`."""
+        w = self._new_wire(val)
+        return Variable({w: 1}, val), w
+
+    # ------------------------------------------------------------------ arithmetic
+    def Add(self, a, b, *rest):
+        res = self._v(a)
+        for x in (b,) + rest:
+            x = self._v(x)
+            if not x.lc:
+                continue
+            if not res.lc:
+                res = x
+                continue
+            if x.is_const():
+                val = self._emit(OP_ADDC, res.val, self._cid(x.const_value()))
+            elif res.is_const():
+                val = self._emit(OP_ADDC, x.val, self._cid(res.const_value()))
+            else:
+                val = self._emit(OP_ADD, res.val, x.val)
+            res = Variable(_lc_add(res.lc, x.lc), val)
+        return res
+
+    def Neg(self, a):
+        a = self._v(a)
+        if not a.lc:
+            return a
+        if a.is_const():
+            return self._const(-a.const_value())
+        return Variable(_lc_scale(a.lc, R - 1), self._emit(OP_NEG, a.val))
+
+    def Sub(self, a, b, *rest):
+        res = self._v(a)
+        for x in (b,) + rest:
+            x = self._v(x)
+            if not x.lc:
+                continue
+            if not res.lc:
+                res = self.Neg(x)
+                continue
+            if x.is_const():
+                val = self._emit(OP_ADDC, res.val, self._cid(-x.const_value()))
+            elif res.is_const():
+                val = self._emit(OP_ADDC, self.Neg(x).val, self._cid(res.const_value()))
+            else:
+                val = self._emit(OP_SUB, res.val, x.val)
+            res = Variable(_lc_add(res.lc, x.lc, -1), val)
+        return res
+
+    def _mul2(self, a, b):
+        a, b = self._v(a), self._v(b)
+        if not a.lc or not b.lc:
+            return self._const(0)
+        if a.is_const() and b.is_const():
+            return self._const(a.const_value() * b.const_value())
+        if a.is_const() or b.is_const():
+            k, x = (a, b) if a.is_const() else (b, a)
+            kv = k.const_value()
+            if kv == 1:
+                return x
+            return Variable(_lc_scale(x.lc, kv), self._emit(OP_MULC, x.val, self._cid(kv)))
+        val = self._emit(OP_MUL, a.val, b.val)
+        res, w = self._internal(val)
+        self._add_r1c(a, b, res, solve_wire=w)
+        return res
+
+    def Mul(self, a, b, *rest):
+        res = self._mul2(a, b)
+        for x in rest:
+            res = self._mul2(res, x)
+        return res
+
+    def MulAcc(self, a, b, c):
+        return self.Add(a, self.Mul(b, c))
+
+    def Inverse(self, a):
+        """res * a == 1 (gnark r1cs builder: one constraint, solved by division)."""
+        a = self._v(a)
+        if a.is_const():
+            if a.const_value() == 0:
+                raise CompileError("inverse of constant zero")
+            return self._const(pow(a.const_value(), R - 2, R))
+        val = self._emit(OP_INV, a.val)
+        res, w = self._internal(val)
+        one = self._const(1)
+        self._add_r1c(res, a, one, solve_wire=w)
+        return res
+
+    def DivUnchecked(self, a, b):
+        """res * b == a (0/0 = 0 as in gnark's solver)."""
+        a, b = self._v(a), self._v(b)
+        if b.is_const():
+            if b.const_value() == 0:
+                raise CompileError("division by constant zero")
+            return self._mul2(a, pow(b.const_value(), R - 2, R))
+        if not a.lc:
+            return self._const(0)
+        val = self._emit(OP_DIV, a.val, b.val)
+        res, w = self._internal(val)
+        self._add_r1c(res, b, a, solve_wire=w)
+        return res
+
+    def Div(self, a, b):
+        """gnark Div: asserts b != 0 by computing its inverse, then multiplies."""
+        a, b = self._v(a), self._v(b)
+        if b.is_const():
+            return self.DivUnchecked(a, b)
+        return self._mul2(a, self.Inverse(b))
+
+    # ------------------------------------------------------------------ booleans
+    def _mark_boolean(self, v):
+        self.booleans.add(self._key(v))
+
+    def _is_boolean(self, v):
+        if v.is_const():
+            return v.const_value() in (0, 1)
+        return self._key(v) in self.booleans
+
+    def AssertIsBoolean(self, a):
+        a = self._v(a)
+        if a.is_const():
+            if a.const_value() not in (0, 1):
+                raise CompileError("constant is not boolean")
+            return
+        if self._is_boolean(a):
+            return
+        self._mark_boolean(a)
+        # a * (1 - a) == 0
+        self._add_r1c(a, self.Sub(1, a), self._zero())
+
+    def _zero(self):
+        if self.val_zero is None:
+            self.val_zero = self._emit(OP_SETC, 0, self._cid(0))
+        return Variable({}, self.val_zero)
+
+    def IsZero(self, a):
+        a = self._v(a)
+        if a.is_const():
+            return self._const(1 if a.const_value() == 0 else 0)
+        # x = 1/a (0 if a == 0) from the InvZero hint; m = 1 - a*x ; a*m == 0
+        xval = self._emit(OP_INV, a.val)
+        x, xw = self._internal(xval)
+        self.hints.append((HINT_INVZERO, [a.lc], [xw]))
+        self.instr.append((1, len(self.hints) - 1))
+        nega = self.Neg(a)
+        cval = self._emit(OP_MUL, nega.val, x.val)          # = m - 1
+        mval = self._emit(OP_ADDC, cval, self._cid(1))
+        m, mw = self._internal(mval)
+        mm1 = Variable(_lc_add(m.lc, {0: 1}, -1), cval)
+        self._add_r1c(nega, x, mm1, solve_wire=mw)
+        self._add_r1c(a, m, self._zero())
+        self._mark_boolean(m)
+        return m
+
+    def Select(self, cond, a, b):
+        cond, a, b = self._v(cond), self._v(a), self._v(b)
+        self.AssertIsBoolean(cond)
+        if cond.is_const():
+            return a if cond.const_value() == 1 else b
+        if a.is_const() and b.is_const():
+            return self.Add(self._mul2(cond, (a.const_value() - b.const_value()) % R), b)
+        return self.Add(self._mul2(cond, self.Sub(a, b)), b)
+
+    def Lookup2(self, b0, b1, i0, i1, i2, i3):
+        """gnark r1cs Lookup2: two constraints."""
+        b0, b1 = self._v(b0), self._v(b1)
+        i0, i1, i2, i3 = (self._v(x) for x in (i0, i1, i2, i3))
+        self.AssertIsBoolean(b0)
+        self.AssertIsBoolean(b1)
+        if b0.is_const() and b1.is_const():
+            return (i0, i1, i2, i3)[b0.const_value() + 2 * b1.const_value()]
+        # tmp = b1 * (i3 - i2 - i1 + i0); res = (tmp + i1 - i0) * b0 + (i2 - i0) * b1 + i0
+        tmp = self.Add(self.Sub(i3, i2, i1), i0)
+        tmp1 = self._mul2(tmp, b1)
+        tmp1 = self.Sub(self.Add(tmp1, i1), i0)
+        tmp2 = self._mul2(tmp1, b0)
+        tmp3 = self._mul2(self.Sub(i2, i0), b1)
+        return self.Add(tmp2, tmp3, i0)
+
+    def And(self, a, b):
+        a, b = self._v(a), self._v(b)
+        self.AssertIsBoolean(a)
+        self.AssertIsBoolean(b)
+        res = self._mul2(a, b)
+        if not res.is_const():
+            self._mark_boolean(res)
+        return res
+
+    def Or(self, a, b):
+        a, b = self._v(a), self._v(b)
+        self.AssertIsBoolean(a)
+        self.AssertIsBoolean(b)
+        # a + b - ab
+        res = self.Sub(self.Add(a, b), self._mul2(a, b))
+        if not res.is_const():
+            self._mark_boolean(res)
+        return res
+
+    def Xor(self, a, b):
+        a, b = self._v(a), self._v(b)
+        self.AssertIsBoolean(a)
+        self.AssertIsBoolean(b)
+        # a + b - 2ab
+        res = self.Sub(self.Add(a, b), self._mul2(self._mul2(a, 2), b))
+        if not res.is_const():
+            self._mark_boolean(res)
+        return res
+
+    # ------------------------------------------------------------------ bits
+    def ToBinary(self, a, n=254):
+        """std/math/bits.ToBinary with WithNbDigits(n): LSB first."""
+        a = self._v(a)
+        if a.is_const():
+            v = a.const_value()
+            if v >> n:
+                raise CompileError("constant does not fit")
+            return [self._const((v >> i) & 1) for i in range(n)]
+        first = self._new_val()
+        vals = [first] + [self._new_val() for _ in range(n - 1)]
+        self.ops.append((OP_BITS, first, a.val, n))
+        wires = [self._new_wire(v) for v in vals]
+        self.hints.append((HINT_NBITS, [a.lc], wires))
+        self.instr.append((1, len(self.hints) - 1))
+        bits = [Variable({w: 1}, v) for w, v in zip(wires, vals)]
+        acc = self._const(0)
+        for i, b in enumerate(bits):
+            self.AssertIsBoolean(b)
+            acc = self.Add(acc, self._mul2(b, pow(2, i, R)))
+        self.AssertIsEqual(acc, a)
+        return bits
+
+    def FromBinary(self, *bits):
+        acc = self._const(0)
+        for i, b in enumerate(bits):
+            b = self._v(b)
+            self.AssertIsBoolean(b)
+            acc = self.Add(acc, self._mul2(b, pow(2, i, R)))
+        return acc
+
+    # ------------------------------------------------------------------ assertions
+    def AssertIsEqual(self, a, b):
+        a, b = self._v(a), self._v(b)
+        if a.is_const() and b.is_const():
+            if a.const_value() != b.const_value():
+                raise CompileError("constants differ")
+            return
+        # encoded 1 * a == b
+        self._add_r1c(self._const(1), a, b)
+
+    def AssertIsDifferent(self, a, b):
+        self.Inverse(self.Sub(a, b))
+
+    def Println(self, *args):
+        self.println_log.append(args)
+
+    def NbConstraints(self):
+        return len(self.constraints)

@@ -1,0 +1,290 @@
+"""``frontend.Compile`` look-alike: circuit definition -> CompiledCircuit (R1CS + witness program).
+
+In the reference every test enters gnark through
+``frontend.Compile(ecc.BN254.ScalarField(), r1cs.NewBuilder, &circuit)``
+(e.g. tree/test/verifier_bn254_test.go:41, hash/native/bn254/poseidon/poseidon_test.go:63) on a
+struct whose ``frontend.Variable`` fields are the inputs (public ones tagged
+``gnark:",public"``) and whose ``Define(api)`` builds the constraints.  Here a circuit is a class
+with ``Public``/``Secret`` field declarations and a ``define(self, api)`` method.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BITS, OP_COPY,
+                  OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULC, OP_NEG, OP_SETC, OP_SUB, R)
+
+
+class _Field:
+    def __init__(self, n=None):
+        self.n = n
+
+
+class Public(_Field):
+    """Public input (gnark struct tag ``gnark:",public"``); ``Public(n)`` declares an array."""
+
+
+class Secret(_Field):
+    """Secret input (gnark's default for an untagged frontend.Variable field)."""
+
+
+def _fields(circuit):
+    out = []
+    for klass in reversed(type(circuit).__mro__):
+        for name, f in vars(klass).items():
+            if isinstance(f, _Field):
+                out.append((name, f))
+    return out
+
+
+def int_to_limbs(x: int) -> np.ndarray:
+    return np.frombuffer(int(x % (1 << 256)).to_bytes(32, "little"), dtype=np.uint64).copy()
+
+
+def ints_to_array(xs) -> np.ndarray:
+    """list of ints -> uint64 [len, 4] little-endian limbs."""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in xs)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def array_to_ints(a: np.ndarray):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    raw = a.tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(a.shape[0])]
+
+
+MONT_R = (1 << 256) % R
+MONT_RINV = pow(MONT_R, R - 2, R)
+
+
+def to_mont_array(xs) -> np.ndarray:
+    return ints_to_array([x % R * MONT_R % R for x in xs])
+
+
+def from_mont_array(a: np.ndarray):
+    return [x * MONT_RINV % R for x in array_to_ints(a)]
+
+
+class CompiledCircuit:
+    """What gnark calls constraint.ConstraintSystem, for this framework.
+
+    R1CS part (consumed by setup and by the oracle): CSR matrices L, R, O over ``n_wires`` columns,
+    coefficient pool, solve order (instructions, hints).
+    Program part (consumed by the GPU solver): uint32 [n_ops, 4] instructions over ``n_slots``
+    value slots; slot i < n_wires *is* wire i.
+    """
+
+    def __init__(self, api: API, layout):
+        self.layout = layout                      # [(name, n|None, public?)]
+        self.n_wires = api.n_wires
+        self.n_public = api.n_public              # includes the ONE wire
+        self.n_secret = api.n_secret
+        self.n_constraints = len(api.constraints)
+        self.n_inputs = api.n_public - 1 + api.n_secret
+        self.consts = list(api.const_list)
+        self.constraints = api.constraints
+        self.instr = np.array(api.instr, dtype=np.uint32).reshape(-1, 2)
+        self.hints = api.hints
+        self._build_csr(api)
+        self._build_program(api)
+
+    # ------------------------------------------------------------------ R1CS
+    def _build_csr(self, api):
+        cid = api._cid
+
+        def csr(sel):
+            ptr, col, c = [0], [], []
+            for con in api.constraints:
+                for w, v in sorted(con[sel].items()):
+                    col.append(w)
+                    c.append(cid(v))
+                ptr.append(len(col))
+            return (np.array(ptr, dtype=np.uint32), np.array(col, dtype=np.uint32),
+                    np.array(c, dtype=np.uint32))
+
+        self.L, self.Rm, self.O = csr(0), csr(1), csr(2)
+        self.solve_wire = np.array([con[3] for con in api.constraints], dtype=np.int32)
+        # hints: kind, inputs (each an LC), outputs
+        kinds, in_ptr, lc_ptr, hcol, hcid, out_ptr, outs = [], [0], [0], [], [], [0], []
+        for kind, ins, ows in api.hints:
+            kinds.append(kind)
+            for lc in ins:
+                for w, v in sorted(lc.items()):
+                    hcol.append(w)
+                    hcid.append(cid(v))
+                lc_ptr.append(len(hcol))
+            in_ptr.append(len(lc_ptr) - 1)
+            outs.extend(ows)
+            out_ptr.append(len(outs))
+        u32 = lambda x: np.array(x, dtype=np.uint32)
+        self.hint_arrays = (u32(kinds), u32(in_ptr), u32(lc_ptr), u32(hcol), u32(hcid),
+                            u32(out_ptr), u32(outs))
+        self.consts = list(api.const_list)  # _cid may have appended
+
+    # ------------------------------------------------------------------ witness program
+    def _build_program(self, api):
+        ops = api.ops
+        n_vals = api.n_vals
+        val_wire = api.val_wire
+        # ---- dead code elimination: roots are constraint operands and wire-backed values
+        live = np.zeros(n_vals + 1, dtype=bool)
+        for v in val_wire:
+            live[v] = True
+        keep = [False] * len(ops)
+        for i in range(len(ops) - 1, -1, -1):
+            op, dst, a, b = ops[i]
+            if op == OP_ABC:
+                keep[i] = True
+                live[dst] = live[a] = live[b] = True
+            elif op == OP_BITS:
+                keep[i] = True
+                live[a] = True
+            elif live[dst]:
+                keep[i] = True
+                if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+                    live[a] = live[b] = True
+                elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY):
+                    live[a] = True
+        ops = [o for o, k in zip(ops, keep) if k]
+        # ---- last use of every value
+        last = {}
+        for i, (op, dst, a, b) in enumerate(ops):
+            if op == OP_ABC:
+                last[dst] = last[a] = last[b] = i
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+                last[a] = last[b] = i
+            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
+                last[a] = i
+        # ---- slot assignment: wire-backed values live in their wire's slot forever; the rest
+        # share a pool of temporaries above n_wires, recycled after the last use
+        slot = dict(val_wire)
+        free, n_slots = [], self.n_wires
+        prog = np.zeros((len(ops) + 1, 4), dtype=np.uint32)
+        for i, (op, dst, a, b) in enumerate(ops):
+            srcs = ()
+            if op == OP_ABC:
+                srcs = (dst, a, b)
+                prog[i] = (op, slot[dst], slot[a], slot[b])
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+                srcs = (a, b)
+            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
+                srcs = (a,)
+            sa = slot[a] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULC, OP_ADDC, OP_NEG,
+                                   OP_INV, OP_COPY, OP_BITS) else 0
+            sb = slot[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV) else b
+            for s in set(srcs):
+                if last.get(s) == i and s not in val_wire:
+                    free.append(slot[s])
+            if op != OP_ABC:
+                if dst not in slot:
+                    if free:
+                        slot[dst] = free.pop()
+                    else:
+                        slot[dst] = n_slots
+                        n_slots += 1
+                    if dst not in last:          # defined, never read (cannot happen after DCE)
+                        free.append(slot[dst])
+                prog[i] = (op, slot[dst], sa, sb)
+        prog[len(ops)] = (OP_END, 0, 0, 0)
+        self.program = prog
+        self.n_slots = n_slots
+        self.n_ops = len(ops)
+
+    # ------------------------------------------------------------------ CPU evaluation
+    def run_program(self, inputs):
+        """Evaluate the witness program with Python integers (debug/test engine only; the product
+        path runs csrc/solve.hip).  Returns (wires, a, b, c) as lists of ints."""
+        if len(inputs) != self.n_inputs:
+            raise ValueError(f"expected {self.n_inputs} inputs, got {len(inputs)}")
+        s = [0] * self.n_slots
+        s[0] = 1
+        for i, v in enumerate(inputs):
+            s[1 + i] = int(v) % R
+        a_, b_, c_ = [], [], []
+        C = self.consts
+        for op, d, a, b in self.program.tolist():
+            if op == OP_MUL:
+                s[d] = s[a] * s[b] % R
+            elif op == OP_ADD:
+                s[d] = (s[a] + s[b]) % R
+            elif op == OP_SUB:
+                s[d] = (s[a] - s[b]) % R
+            elif op == OP_MULC:
+                s[d] = s[a] * C[b] % R
+            elif op == OP_ADDC:
+                s[d] = (s[a] + C[b]) % R
+            elif op == OP_ABC:
+                a_.append(s[d])
+                b_.append(s[a])
+                c_.append(s[b])
+            elif op == OP_NEG:
+                s[d] = (-s[a]) % R
+            elif op == OP_SETC:
+                s[d] = C[b]
+            elif op == OP_INV:
+                s[d] = pow(s[a], R - 2, R)
+            elif op == OP_DIV:
+                s[d] = s[a] * pow(s[b], R - 2, R) % R
+            elif op == OP_BITS:
+                v = s[a]
+                for k in range(b):
+                    s[d + k] = (v >> k) & 1
+            elif op == OP_COPY:
+                s[d] = s[a]
+            elif op == OP_END:
+                break
+        return s[:self.n_wires], a_, b_, c_
+
+    def is_satisfied(self, wires):
+        """Check every constraint <L,w>*<R,w> == <O,w> on a full wire assignment."""
+        for k, (L, Rr, O, _, _) in enumerate(self.constraints):
+            ev = lambda lc: sum(c * wires[w] for w, c in lc.items()) % R
+            if ev(L) * ev(Rr) % R != ev(O):
+                return False, k
+        return True, -1
+
+    def domain_log2(self):
+        n = max(self.n_constraints, 2)
+        return (n - 1).bit_length()
+
+    def assignment_vector(self, assignment: dict):
+        """dict field name -> int | list[int]  ->  flat input vector in wire order."""
+        out = []
+        for name, n, _ in self.layout:
+            v = assignment[name]
+            if n is None:
+                out.append(int(v) % R)
+            else:
+                if len(v) != n:
+                    raise ValueError(f"{name}: expected {n} values")
+                out.extend(int(x) % R for x in v)
+        return out
+
+    def fingerprint(self) -> str:
+        h = hashlib.sha256()
+        for arr in (*self.L, *self.Rm, *self.O, self.program):
+            h.update(np.ascontiguousarray(arr).tobytes())
+        h.update(repr(self.consts).encode())
+        return h.hexdigest()[:16]
+
+
+def compile_circuit(circuit) -> CompiledCircuit:
+    """``frontend.Compile(field, r1cs.NewBuilder, circuit)`` for BN254's scalar field."""
+    api = API()
+    fields = _fields(circuit)
+    layout = []
+    # gnark wire order: ONE, public..., secret..., internal...
+    for want_public in (True, False):
+        for name, f in fields:
+            if isinstance(f, Public) != want_public:
+                continue
+            mk = api.public_input if want_public else api.secret_input
+            if f.n is None:
+                setattr(circuit, name, mk(name))
+            else:
+                setattr(circuit, name, [mk(f"{name}[{i}]") for i in range(f.n)])
+            layout.append((name, f.n, want_public))
+    circuit.define(api)
+    return CompiledCircuit(api, layout)

@@ -1,0 +1,208 @@
+"""ctypes binding of libzkmi.so (include/zkmi.h).  Loading fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+
+ZKMI_OK = 0
+ZKMI_ERR_UNSATISFIED = -5
+
+
+class ZkmiError(RuntimeError):
+    pass
+
+
+class PkDesc(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("n_wires", C.c_uint32), ("n_a", C.c_uint32),
+                ("n_b", C.c_uint32), ("n_k", C.c_uint32), ("n_z", C.c_uint32),
+                ("a_wire", C.c_void_p), ("b_wire", C.c_void_p), ("k_wire", C.c_void_p),
+                ("g1_a", C.c_void_p), ("g1_b", C.c_void_p), ("g1_k", C.c_void_p),
+                ("g1_z", C.c_void_p), ("g2_b", C.c_void_p), ("g1_alpha", C.c_void_p),
+                ("g1_beta", C.c_void_p), ("g1_delta", C.c_void_p), ("g2_beta", C.c_void_p),
+                ("g2_delta", C.c_void_p), ("window_bits_g1", C.c_uint32),
+                ("window_bits_g2", C.c_uint32)]
+
+
+class CsDesc(C.Structure):
+    _fields_ = [("n_wires", C.c_uint32), ("n_public", C.c_uint32), ("n_secret", C.c_uint32),
+                ("n_constraints", C.c_uint32), ("n_slots", C.c_uint32), ("n_ops", C.c_uint32),
+                ("n_consts", C.c_uint32), ("_pad", C.c_uint32), ("program", C.c_void_p),
+                ("consts", C.c_void_p)]
+
+
+# every symbol include/zkmi.h declares: (name, restype, argtypes)
+_P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
+SYMBOLS = [
+    ("zkmi_init", _I, [_I, C.POINTER(_P)]),
+    ("zkmi_destroy", None, [_P]),
+    ("zkmi_last_error", C.c_char_p, [_P]),
+    ("zkmi_sync", _I, [_P]),
+    ("zkmi_stream", _P, [_P]),
+    ("zkmi_field_mul", _I, [_P, _I, _P, _P, _P, _SZ]),
+    ("zkmi_field_mul_bench", _I, [_P, _I, _SZ, _I, C.POINTER(C.c_double)]),
+    ("zkmi_ntt_batch", _I, [_P, _P, _I, _SZ, _I, _I]),
+    ("zkmi_h_batch", _I, [_P, _P, _P, _P, _P, _I, _SZ]),
+    ("zkmi_msm_bases_load", _I, [_P, _I, _P, _SZ, _I, C.POINTER(_P)]),
+    ("zkmi_msm_bases_free", None, [_P, _P]),
+    ("zkmi_msm_batch", _I, [_P, _P, _P, _SZ, _P]),
+    ("zkmi_fixed_base_mul", _I, [_P, _I, _P, _P, _SZ, _P]),
+    ("zkmi_pk_load", _I, [_P, C.POINTER(PkDesc), C.POINTER(_P)]),
+    ("zkmi_pk_free", None, [_P, _P]),
+    ("zkmi_cs_load", _I, [_P, C.POINTER(CsDesc), C.POINTER(_P)]),
+    ("zkmi_cs_free", None, [_P, _P]),
+    ("zkmi_solve_batch", _I, [_P, _P, _P, _SZ, _P, _P, _P]),
+    ("zkmi_prove_batch", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P]),
+    ("zkmi_last_timings", _I, [_P, C.POINTER(C.c_double)]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libzkmi.so and bind every declared symbol; raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZkmiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as "
+                        "g; g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(x):
+    """numpy array / torch tensor / int -> raw address (host or device)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    return int(x)
+
+
+class Context:
+    """One per GPU (zkmi_init / zkmi_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.zkmi_init(device, C.byref(h))
+        if rc != 0:
+            raise ZkmiError(f"zkmi_init(device={device}) failed with {rc} "
+                            "(-3 = no HIP device: this library only runs on a GPU)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkmi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.zkmi_last_error(self.h)
+            raise ZkmiError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def sync(self):
+        self._check(self.lib.zkmi_sync(self.h), "zkmi_sync")
+
+    def stream(self) -> int:
+        return self.lib.zkmi_stream(self.h) or 0
+
+    # ---- primitives
+    def field_mul(self, which, a, b, out=None):
+        n = a.shape[0]
+        out = np.empty_like(a) if out is None else out
+        self._check(self.lib.zkmi_field_mul(self.h, which, _ptr(a), _ptr(b), _ptr(out), n),
+                    "zkmi_field_mul")
+        return out
+
+    def field_mul_bench(self, which=1, n_threads=1 << 20, iters=256) -> float:
+        r = C.c_double()
+        self._check(self.lib.zkmi_field_mul_bench(self.h, which, n_threads, iters, C.byref(r)),
+                    "zkmi_field_mul_bench")
+        return r.value
+
+    def ntt_batch(self, data, log_n, batch, inverse=False, coset=False):
+        self._check(self.lib.zkmi_ntt_batch(self.h, _ptr(data), log_n, batch, int(inverse),
+                                            int(coset)), "zkmi_ntt_batch")
+        return data
+
+    def h_batch(self, a, b, c, out, log_n, batch):
+        self._check(self.lib.zkmi_h_batch(self.h, _ptr(a), _ptr(b), _ptr(c), _ptr(out), log_n,
+                                          batch), "zkmi_h_batch")
+        return out
+
+    def msm_bases_load(self, group, bases, n, window_bits=0):
+        h = C.c_void_p()
+        self._check(self.lib.zkmi_msm_bases_load(self.h, group, _ptr(bases), n, window_bits,
+                                                 C.byref(h)), "zkmi_msm_bases_load")
+        return h
+
+    def msm_bases_free(self, h):
+        self.lib.zkmi_msm_bases_free(self.h, h)
+
+    def msm_batch(self, bases_h, scalars, batch, out):
+        self._check(self.lib.zkmi_msm_batch(self.h, bases_h, _ptr(scalars), batch, _ptr(out)),
+                    "zkmi_msm_batch")
+        return out
+
+    def fixed_base_mul(self, group, base, scalars, n, out):
+        self._check(self.lib.zkmi_fixed_base_mul(self.h, group, _ptr(base), _ptr(scalars), n,
+                                                 _ptr(out)), "zkmi_fixed_base_mul")
+        return out
+
+    # ---- key / system handles
+    def pk_load(self, desc: PkDesc):
+        h = C.c_void_p()
+        self._check(self.lib.zkmi_pk_load(self.h, C.byref(desc), C.byref(h)), "zkmi_pk_load")
+        return h
+
+    def pk_free(self, h):
+        self.lib.zkmi_pk_free(self.h, h)
+
+    def cs_load(self, desc: CsDesc):
+        h = C.c_void_p()
+        self._check(self.lib.zkmi_cs_load(self.h, C.byref(desc), C.byref(h)), "zkmi_cs_load")
+        return h
+
+    def cs_free(self, h):
+        self.lib.zkmi_cs_free(self.h, h)
+
+    def solve_batch(self, cs_h, inputs, batch, wires_out=None, abc_out=None, status_out=None):
+        if status_out is None:
+            status_out = np.zeros(batch, dtype=np.int32)
+        self._check(self.lib.zkmi_solve_batch(self.h, cs_h, _ptr(inputs), batch, _ptr(wires_out),
+                                              _ptr(abc_out), _ptr(status_out)), "zkmi_solve_batch")
+        return status_out
+
+    def prove_batch(self, pk_h, cs_h, inputs, batch, rs, proofs_out, status_out):
+        self._check(self.lib.zkmi_prove_batch(self.h, pk_h, cs_h, _ptr(inputs), batch, _ptr(rs),
+                                              _ptr(proofs_out), _ptr(status_out)),
+                    "zkmi_prove_batch")
+
+    def last_timings(self):
+        arr = (C.c_double * 8)()
+        self.lib.zkmi_last_timings(self.h, arr)
+        return list(arr)

@@ -1,0 +1,151 @@
+/* zkmi.h -- C-ABI of the MI355X-native Groth16/BN254 prover hot path (libzkmi.so).
+ *
+ * The reference (vocdoni/gnark-crypto-primitives) has no FFI boundary of its own: its circuits
+ * reach the prover only through gnark (go.mod:8-9) from test call sites such as
+ * tree/test/verifier_bn254_test.go:41 (frontend.Compile) and :67 (assert.SolvingSucceeded ->
+ * solver; groth16.Prove under the prover_checks build tag).  Each entry point below names the
+ * gnark / gnark-crypto interface it stands in for [UPSTREAM-RECALL, SURVEY.md §3.2, §8b]; the cgo
+ * stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions (chosen so a cgo caller passes unsafe.Pointer(&slice[0]) with zero copies):
+ *   - fr.Element / fp.Element: 4 x uint64 little-endian limbs, Montgomery form, R = 2^256.
+ *   - G1Affine = {X, Y} 64 B; G2Affine = {X.A0, X.A1, Y.A0, Y.A1} 128 B; infinity = all zero.
+ *   - Every pointer argument may be a host pointer or a HIP device pointer (detected with
+ *     hipPointerGetAttributes); device pointers avoid the PCIe copy.
+ *   - "batch" arrays are proof-major: element (proof p, index i) at [p * stride + i].
+ *   - All functions return 0 on success or a negative zkmi_status; they never abort.  A context
+ *     is thread-compatible (one caller at a time); distinct contexts are independent.
+ */
+#ifndef ZKMI_H
+#define ZKMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkmi_ctx zkmi_ctx;
+typedef struct zkmi_pk zkmi_pk;
+typedef struct zkmi_cs zkmi_cs;
+
+enum zkmi_status {
+  ZKMI_OK = 0,
+  ZKMI_ERR_ARG = -1,
+  ZKMI_ERR_HIP = -2,
+  ZKMI_ERR_NO_DEVICE = -3,
+  ZKMI_ERR_OOM = -4,
+  ZKMI_ERR_UNSATISFIED = -5 /* at least one proof's witness does not satisfy the system */
+};
+
+/* -- context ----------------------------------------------------------------------------- */
+/* Selects HIP device `device`, creates the streams and the NTT twiddle cache.  Fails with
+ * ZKMI_ERR_NO_DEVICE when no gfx950 device is visible: there is no CPU fallback. */
+int zkmi_init(int device, zkmi_ctx** out);
+void zkmi_destroy(zkmi_ctx* ctx);
+const char* zkmi_last_error(zkmi_ctx* ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int zkmi_sync(zkmi_ctx* ctx);
+/* HIP stream (hipStream_t) the context launches on -- for callers that time with HIP events. */
+void* zkmi_stream(zkmi_ctx* ctx);
+
+/* -- field / group primitives (parity tests; a Go shim that keeps gnark's own solver) ------- */
+/* r[i] = a[i] * b[i] in fr (which = 0) or fp (which = 1).   stands in for fr.Element.Mul / fp.Element.Mul */
+int zkmi_field_mul(zkmi_ctx* ctx, int which, const void* a, const void* b, void* r, size_t n);
+/* Throughput microbenchmark: every lane runs `iters` dependent Montgomery products; returns
+ * products per second in *rate (integer-ALU roofline measurement). */
+int zkmi_field_mul_bench(zkmi_ctx* ctx, int which, size_t n_threads, int iters, double* rate);
+
+/* Batched NTT over fr, natural order in and out, in place.  stands in for
+ * fft.Domain.FFT / FFTInverse (gnark-crypto ecc/bn254/fr/fft) with fft.OnCoset() = `coset`.
+ *   data: batch x 2^log_n fr elements, proof-major. */
+int zkmi_ntt_batch(zkmi_ctx* ctx, void* data, int log_n, size_t batch, int inverse, int coset);
+
+/* h = coefficients of (A.B - C)/Z_H.   stands in for computeH in gnark
+ * backend/groth16/bn254/prove.go.  a, b, c: batch x 2^log_n evaluations (zero padded);
+ * h_out: batch x 2^log_n coefficients, natural order. */
+int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, void* h_out,
+                 int log_n, size_t batch);
+
+/* Fixed-base MSM handle: bases are uploaded once and expanded into the HBM-resident window
+ * table.  group: 1 = G1, 2 = G2.  window_bits = 0 picks a default. */
+typedef struct zkmi_msm_bases zkmi_msm_bases;
+int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
+                        zkmi_msm_bases** out);
+void zkmi_msm_bases_free(zkmi_ctx* ctx, zkmi_msm_bases* b);
+/* out[p] = sum_i scalars[p][i] * bases[i].   stands in for G1Jac/G2Jac.MultiExp (gnark-crypto
+ * ecc/bn254/multiexp.go) called once per proof with the same bases.
+ *   scalars: batch x n fr elements (Montgomery), proof-major; out: batch affine points. */
+int zkmi_msm_batch(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const void* scalars, size_t batch,
+                   void* out);
+/* out[i] = scalars[i] * base.   stands in for curve.BatchScalarMultiplicationG1/G2 used by
+ * groth16.Setup (gnark backend/groth16/bn254/setup.go). */
+int zkmi_fixed_base_mul(zkmi_ctx* ctx, int group, const void* base, const void* scalars, size_t n,
+                        void* out);
+
+/* -- proving key --------------------------------------------------------------------------- */
+/* Mirrors gnark's groth16 bn254 ProvingKey: Domain, G1{Alpha,Beta,Delta,A,B,Z,K}, G2{Beta,Delta,B},
+ * InfinityA/B expressed as the wire index of every retained base. */
+typedef struct {
+  uint32_t log_n;       /* domain size 2^log_n */
+  uint32_t n_wires;     /* columns of the constraint system, including ONE */
+  uint32_t n_a, n_b, n_k, n_z;
+  const uint32_t* a_wire; /* n_a: wire index of g1_a[i] (InfinityA filtered out) */
+  const uint32_t* b_wire; /* n_b: wire index of g1_b[i] and g2_b[i] */
+  const uint32_t* k_wire; /* n_k: wire index of g1_k[i] (private wires) */
+  const void* g1_a;
+  const void* g1_b;
+  const void* g1_k;
+  const void* g1_z; /* n_z = 2^log_n - 1 */
+  const void* g2_b;
+  const void* g1_alpha;
+  const void* g1_beta;
+  const void* g1_delta;
+  const void* g2_beta;
+  const void* g2_delta;
+  uint32_t window_bits_g1; /* 0 = default */
+  uint32_t window_bits_g2;
+} zkmi_pk_desc;
+/* Copies the key to the device and builds the MSM window tables; host buffers may be freed
+ * afterwards.  One-off per circuit (gnark's icicle backend does the same lazily). */
+int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* desc, zkmi_pk** out);
+void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk);
+
+/* -- constraint system (witness program) ----------------------------------------------------- */
+/* What cs.R1CS.Solve needs, in the straight-line form produced by
+ * gnark_crypto_primitives_amd.frontend.compile_circuit. */
+typedef struct {
+  uint32_t n_wires, n_public, n_secret, n_constraints;
+  uint32_t n_slots, n_ops, n_consts, _pad;
+  const uint32_t* program; /* (n_ops + 1) x 4 words */
+  const void* consts;      /* n_consts fr elements, Montgomery */
+} zkmi_cs_desc;
+int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* desc, zkmi_cs** out);
+void zkmi_cs_free(zkmi_ctx* ctx, zkmi_cs* cs);
+
+/* Witness solve only.  stands in for cs.R1CS.Solve (gnark constraint/bn254).
+ *   inputs: batch x (n_public - 1 + n_secret) fr elements, Montgomery, proof-major
+ *   wires_out (optional): batch x n_wires ; abc_out (optional): 3 x batch x n_constraints
+ *   status_out: per proof, 0 or ZKMI_ERR_UNSATISFIED */
+int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_t batch,
+                     void* wires_out, void* abc_out, int32_t* status_out);
+
+/* Full Groth16 prove for a batch of independent witnesses.  stands in for groth16.Prove(ccs, pk,
+ * fullWitness) called `batch` times (gnark backend/groth16/bn254/prove.go).
+ *   inputs: as zkmi_solve_batch
+ *   rs: batch x 2 fr elements (Montgomery): the prover's blinding scalars r, s.  gnark samples
+ *       them inside Prove; they are an input here so results are reproducible.
+ *   proofs_out: batch x 256 B: Ar (G1) | Krs (G1) | Bs (G2), the field order of gnark's Proof
+ *   status_out: per proof */
+int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
+                     size_t batch, const void* rs, void* proofs_out, int32_t* status_out);
+
+/* Per-stage device time of the last zkmi_prove_batch, milliseconds, measured with HIP events on
+ * the context's stream: [0] solve, [1] quotient (NTTs + pointwise), [2] G1 MSMs, [3] G2 MSM,
+ * [4] assembly, [5] total.  Also reports the MSM kernel's own launch count and time. */
+int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out /* 8 doubles */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
