@@ -193,6 +193,10 @@ int zkmi_init(int device, zkmi_ctx** out) {
     return ZKMI_ERR_HIP;
   }
   for (auto& e : ctx->ev) hipEventCreate(&e);
+  for (auto& p : ctx->msm_ev) {
+    hipEventCreate(&p[0]);
+    hipEventCreate(&p[1]);
+  }
   ctx->plans.reserve(32);
   *out = ctx;
   return ZKMI_OK;
@@ -212,6 +216,10 @@ void zkmi_destroy(zkmi_ctx* ctx) {
     if (s.p) hipFree(s.p);
   for (auto& e : ctx->ev)
     if (e) hipEventDestroy(e);
+  for (auto& p : ctx->msm_ev) {
+    if (p[0]) hipEventDestroy(p[0]);
+    if (p[1]) hipEventDestroy(p[1]);
+  }
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -434,14 +442,19 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   pk->n_k = d->n_k;
   pk->n_z = d->n_z;
   int rc;
+  // one window size per group for the whole key, sized against free HBM
+  const int c1 = d->window_bits_g1
+                     ? (int)d->window_bits_g1
+                     : default_window((size_t)d->n_a + d->n_b + d->n_k + d->n_z, 1);
+  const int c2 = d->window_bits_g2 ? (int)d->window_bits_g2 : default_window(d->n_b, 2);
   if ((rc = upload_u32(ctx, d->a_wire, d->n_a, &pk->a_wire)) ||
       (rc = upload_u32(ctx, d->b_wire, d->n_b, &pk->b_wire)) ||
       (rc = upload_u32(ctx, d->k_wire, d->n_k, &pk->k_wire)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_a, d->n_a, d->window_bits_g1, &pk->A)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_b, d->n_b, d->window_bits_g1, &pk->B1)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_k, d->n_k, d->window_bits_g1, &pk->K)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_z, d->n_z, d->window_bits_g1, &pk->Z)) ||
-      (rc = zkmi_msm_bases_load(ctx, 2, d->g2_b, d->n_b, d->window_bits_g2, &pk->B2))) {
+      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_a, d->n_a, c1, &pk->A)) ||
+      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_b, d->n_b, c1, &pk->B1)) ||
+      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_k, d->n_k, c1, &pk->K)) ||
+      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_z, d->n_z, c1, &pk->Z)) ||
+      (rc = zkmi_msm_bases_load(ctx, 2, d->g2_b, d->n_b, c2, &pk->B2))) {
     zkmi_pk_free(ctx, pk);
     return rc;
   }
@@ -624,6 +637,8 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
   if ((rc = compute_h_bi(ctx, plan, (Fr*)a, (Fr*)b, (Fr*)c, (Fr*)t0, Bp, cs->n_constraints, &h)))
     return rc;
   hipEventRecord(ctx->ev[2], ctx->stream);
+  ctx->msm_ev_used = 0;
+  ctx->msm_ev_on = true;
   if ((rc = msm_run(ctx, pk->A, (const Fr*)slots, pk->a_wire, Bp, sA)) ||
       (rc = msm_run(ctx, pk->B1, (const Fr*)slots, pk->b_wire, Bp, sB1)) ||
       (rc = msm_run(ctx, pk->K, (const Fr*)slots, pk->k_wire, Bp, sK)) ||
@@ -632,6 +647,7 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
   hipEventRecord(ctx->ev[3], ctx->stream);
   if ((rc = msm_run(ctx, pk->B2, (const Fr*)slots, pk->b_wire, Bp, sB2))) return rc;
   hipEventRecord(ctx->ev[4], ctx->stream);
+  ctx->msm_ev_on = false;
   PkConsts pc{pk->alpha, pk->beta1, pk->delta1, pk->beta2, pk->delta2};
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, sA, sB1,
                      sK, sZ, sB2, rs_bi, Bp, pc, proofs);
@@ -651,6 +667,12 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
   float tot = 0;
   hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[5]);
   ctx->timings[5] = tot;
+  ctx->timings[6] = ctx->timings[7] = 0;
+  for (int i = 0; i < ctx->msm_ev_used; i++) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->msm_ev[i][0], ctx->msm_ev[i][1]);
+    ctx->timings[ctx->msm_ev_group[i] == 1 ? 6 : 7] += ms;
+  }
   // per-proof status is reported in status_out; the call itself succeeded
   return ZKMI_OK;
 }

@@ -135,9 +135,12 @@ __global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __res
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-static int default_window(size_t n, int group) {
-  // keep the table under ~96 GB for G1 and ~48 GB for G2 (the Arbo-160 key then takes c = 10 / 9)
-  const double budget = group == 1 ? 96e9 : 48e9;
+// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 15 %
+// for its G2 bases (Arbo-160 on a 288 GB MI355X: c = 10 for G1, c = 9 for G2).
+int default_window(size_t n, int group) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+  const double budget = (group == 1 ? 0.60 : 0.15) * (double)free_b;
   const double entry = group == 1 ? 64.0 : 128.0;
   int best = 4;
   for (int c = 4; c <= 12; c++) {
@@ -227,9 +230,15 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   int rc = ensure_scratch(ctx, 6, chunks * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
   const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
+  const int ev = (ctx->msm_ev_on && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
+  if (ev >= 0) {
+    ctx->msm_ev_group[ev] = bases->group;
+    hipEventRecord(ctx->msm_ev[ev][0], ctx->stream);
+  }
   hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx), 0,
                      ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
                      (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
   hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
                      (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, out);
   ZK_HIP(hipGetLastError());

@@ -42,6 +42,11 @@ struct zkmi_ctx {
   double timings[8] = {};
   // scratch arena for the prove pipeline, grown on demand
   zk::DevBuf scratch[8];
+  // HIP event pairs bracketing every msm_accumulate launch of the current prove call
+  hipEvent_t msm_ev[16][2] = {};
+  int msm_ev_group[16] = {};
+  int msm_ev_used = 0;
+  bool msm_ev_on = false;
 };
 
 struct zkmi_msm_bases {
@@ -106,6 +111,7 @@ int compute_h_bi(zkmi_ctx* ctx, const NttPlan* plan, Fr* a, Fr* b, Fr* c, Fr* t0
                  size_t n_valid, Fr** h_out);
 
 // msm.hip
+int default_window(size_t n_bases_total, int group);
 int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, int c,
                     zkmi_msm_bases** out);
 // scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)

@@ -76,7 +76,7 @@ class API:
         self.n_wires = 1            # wire 0 = ONE
         self.n_public = 1
         self.n_secret = 0
-        self.constraints = []       # (L, R, O, solve_wire, (va, vb, vc))
+        self.constraints = []       # (L, R, O, solve_wire, (va, vb, vc), check)
         self.instr = []             # (kind, index): 0 = R1C, 1 = hint
         self.hints = []             # (kind, [input lc], [output wires])
         self.ops = []               # SSA ops: (opcode, dst_val, a, b) ; see _emit
@@ -158,10 +158,14 @@ class API:
     def _key(v):
         return tuple(sorted(v.lc.items()))
 
-    def _add_r1c(self, L, R_, O, solve_wire=-1):
+    def _add_r1c(self, L, R_, O, solve_wire=-1, check=None):
+        """check: the solver must verify L*R == O (assertions; divisions, where a zero divisor
+        makes the defining equation unsatisfiable)."""
         self._inputs_open = False
         k = len(self.constraints)
-        self.constraints.append((L.lc, R_.lc, O.lc, solve_wire, (L.val, R_.val, O.val)))
+        if check is None:
+            check = solve_wire < 0
+        self.constraints.append((L.lc, R_.lc, O.lc, solve_wire, (L.val, R_.val, O.val), check))
         self.instr.append((0, k))
         self._emit(OP_ABC, R_.val, O.val, dst=L.val)   # (sa, sb, sc) = (dst, a, b)
         return k
@@ -252,7 +256,7 @@ class API:
         val = self._emit(OP_INV, a.val)
         res, w = self._internal(val)
         one = self._const(1)
-        self._add_r1c(res, a, one, solve_wire=w)
+        self._add_r1c(res, a, one, solve_wire=w, check=True)
         return res
 
     def DivUnchecked(self, a, b):
@@ -266,7 +270,7 @@ class API:
             return self._const(0)
         val = self._emit(OP_DIV, a.val, b.val)
         res, w = self._internal(val)
-        self._add_r1c(res, b, a, solve_wire=w)
+        self._add_r1c(res, b, a, solve_wire=w, check=True)
         return res
 
     def Div(self, a, b):

@@ -162,11 +162,15 @@ class CompiledCircuit:
         slot = dict(val_wire)
         free, n_slots = [], self.n_wires
         prog = np.zeros((len(ops) + 1, 4), dtype=np.uint32)
+        n_abc = 0
         for i, (op, dst, a, b) in enumerate(ops):
             srcs = ()
             if op == OP_ABC:
                 srcs = (dst, a, b)
-                prog[i] = (op, slot[dst], slot[a], slot[b])
+                # bit 8: the solver verifies this row (assertion / division)
+                flag = 0x100 if api.constraints[n_abc][5] else 0
+                n_abc += 1
+                prog[i] = (op | flag, slot[dst], slot[a], slot[b])
             elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
                 srcs = (a, b)
             elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
@@ -204,7 +208,9 @@ class CompiledCircuit:
             s[1 + i] = int(v) % R
         a_, b_, c_ = [], [], []
         C = self.consts
+        self.last_status = 0
         for op, d, a, b in self.program.tolist():
+            chk, op = op & 0x100, op & 0xff
             if op == OP_MUL:
                 s[d] = s[a] * s[b] % R
             elif op == OP_ADD:
@@ -219,6 +225,8 @@ class CompiledCircuit:
                 a_.append(s[d])
                 b_.append(s[a])
                 c_.append(s[b])
+                if chk and s[d] * s[a] % R != s[b]:
+                    self.last_status = -5
             elif op == OP_NEG:
                 s[d] = (-s[a]) % R
             elif op == OP_SETC:
@@ -239,7 +247,7 @@ class CompiledCircuit:
 
     def is_satisfied(self, wires):
         """Check every constraint <L,w>*<R,w> == <O,w> on a full wire assignment."""
-        for k, (L, Rr, O, _, _) in enumerate(self.constraints):
+        for k, (L, Rr, O, *_) in enumerate(self.constraints):
             ev = lambda lc: sum(c * wires[w] for w, c in lc.items()) % R
             if ev(L) * ev(Rr) % R != ev(O):
                 return False, k

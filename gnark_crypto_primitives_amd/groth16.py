@@ -1,0 +1,199 @@
+"""Groth16 over BN254: host-side mirror of gnark's ``backend/groth16`` for this framework.
+
+* ``setup``   -- groth16.Setup (gnark backend/groth16/bn254/setup.go [UPSTREAM-RECALL]): trapdoor
+  sampled from a seed, QAP evaluated at tau in Python ints, group elements produced by the GPU
+  fixed-base kernel (``zkmi_fixed_base_mul``) or any ``mul(group, scalars) -> points`` callable.
+  Key layout follows gnark's ProvingKey: G1{Alpha,Beta,Delta,A,B,Z,K}, G2{Beta,Delta,B}, with
+  the InfinityA/B bitmaps expressed as the wire index of every retained point.
+* ``Prover``  -- groth16.Prove for a *batch* of independent witnesses on one GPU: uploads the key
+  once (zkmi_pk_load builds the HBM window tables), the constraint system once (zkmi_cs_load),
+  then every ``prove`` call is one zkmi_prove_batch.  No CPU fallback.
+
+Reference call sites this replaces: the ``test.Assert`` prover checks, e.g.
+hash/emulated/bn254/poseidon/poseidon_test.go:72 (ProverSucceeded) and, under gnark's
+``prover_checks`` tag, every SolvingSucceeded site such as tree/test/verifier_bn254_test.go:67.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+
+import numpy as np
+
+from . import lib as _lib
+from .frontend.compile import CompiledCircuit, R, ints_to_array, to_mont_array
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+_MONT_P = (1 << 256) % P
+
+G1_GEN = (1, 2)
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def _fq_mont(xs):
+    return ints_to_array([x % P * _MONT_P % P for x in xs])
+
+
+def g1_gen_mont():
+    return _fq_mont(G1_GEN).reshape(-1)
+
+
+def g2_gen_mont():
+    return _fq_mont([G2_GEN[0][0], G2_GEN[0][1], G2_GEN[1][0], G2_GEN[1][1]]).reshape(-1)
+
+
+def _inv(x):
+    return pow(x % R, R - 2, R)
+
+
+def root_of_unity(log_n):
+    return pow(pow(5, (R - 1) >> 28, R), 1 << (28 - log_n), R)
+
+
+class ProvingKey:
+    """gnark groth16 (bn254) ProvingKey, numpy arrays in gnark's memory layout (Montgomery)."""
+
+    def __init__(self):
+        self.log_n = 0
+        self.n_wires = 0
+        self.a_wire = self.b_wire = self.k_wire = None     # uint32
+        self.g1_a = self.g1_b = self.g1_k = self.g1_z = self.g2_b = None
+        self.g1_alpha = self.g1_beta = self.g1_delta = self.g2_beta = self.g2_delta = None
+
+    def nbytes(self):
+        return sum(x.nbytes for x in (self.g1_a, self.g1_b, self.g1_k, self.g1_z, self.g2_b))
+
+
+class VerifyingKey:
+    def __init__(self):
+        self.g1_alpha = self.g2_beta = self.g2_gamma = self.g2_delta = None
+        self.g1_k = None            # one point per public wire (ONE first)
+
+
+def sample_trapdoor(seed):
+    rng = random.Random(seed)
+    return tuple(rng.randrange(1, R) for _ in range(5))   # tau, alpha, beta, gamma, delta
+
+
+def setup(cc: CompiledCircuit, seed, mul):
+    """(pk, vk, trapdoor).  ``mul(group, scalars_mont[n,4]) -> points`` multiplies the group
+    generator by each scalar (gnark: curve.BatchScalarMultiplicationG1/G2)."""
+    tau, alpha, beta, gamma, delta = trapdoor = sample_trapdoor(seed)
+    log_n = cc.domain_log2()
+    n = 1 << log_n
+    nw = cc.n_wires
+    # Lagrange basis at tau for the constraint rows in use
+    w = root_of_unity(log_n)
+    zt = (pow(tau, n, R) - 1) % R
+    if zt == 0:
+        raise ValueError("tau lies in the evaluation domain")
+    ninv = _inv(n)
+    A, B, Cc = [0] * nw, [0] * nw, [0] * nw
+    wk = 1
+    for con in cc.constraints:
+        lk = zt * wk % R * ninv % R * _inv(tau - wk) % R
+        for vec, lc in ((A, con[0]), (B, con[1]), (Cc, con[2])):
+            for wi, c in lc.items():
+                vec[wi] = (vec[wi] + c * lk) % R
+        wk = wk * w % R
+    dinv, ginv = _inv(delta), _inv(gamma)
+    pk, vk = ProvingKey(), VerifyingKey()
+    pk.log_n, pk.n_wires = log_n, nw
+    a_wire = [i for i in range(nw) if A[i]]
+    b_wire = [i for i in range(nw) if B[i]]
+    k_wire = list(range(cc.n_public, nw))
+    pk.a_wire = np.array(a_wire, dtype=np.uint32)
+    pk.b_wire = np.array(b_wire, dtype=np.uint32)
+    pk.k_wire = np.array(k_wire, dtype=np.uint32)
+    kk = [(beta * A[i] + alpha * B[i] + Cc[i]) % R for i in range(nw)]
+    z = []
+    t = zt * dinv % R
+    for _ in range(n - 1):
+        z.append(t)
+        t = t * tau % R
+    g1_scalars = ([A[i] for i in a_wire] + [B[i] for i in b_wire] +
+                  [kk[i] * dinv % R for i in k_wire] + z +
+                  [kk[i] * ginv % R for i in range(cc.n_public)] + [alpha, beta, delta])
+    g1_pts = mul(1, to_mont_array(g1_scalars))
+    o = 0
+
+    def take(cnt):
+        nonlocal o
+        r = np.ascontiguousarray(g1_pts[o:o + cnt])
+        o += cnt
+        return r
+    pk.g1_a, pk.g1_b, pk.g1_k, pk.g1_z = (take(len(a_wire)), take(len(b_wire)), take(len(k_wire)),
+                                          take(n - 1))
+    vk.g1_k = take(cc.n_public)
+    pk.g1_alpha, pk.g1_beta, pk.g1_delta = (take(1).reshape(-1) for _ in range(3))
+    vk.g1_alpha = pk.g1_alpha
+    g2_pts = mul(2, to_mont_array([B[i] for i in b_wire] + [beta, delta, gamma]))
+    nb = len(b_wire)
+    pk.g2_b = np.ascontiguousarray(g2_pts[:nb])
+    pk.g2_beta, pk.g2_delta = g2_pts[nb].copy(), g2_pts[nb + 1].copy()
+    vk.g2_beta, vk.g2_delta, vk.g2_gamma = pk.g2_beta, pk.g2_delta, g2_pts[nb + 2].copy()
+    return pk, vk, trapdoor
+
+
+def gpu_mul(ctx: _lib.Context):
+    """``mul`` callable for ``setup`` backed by zkmi_fixed_base_mul."""
+    def mul(group, scalars):
+        n = scalars.shape[0]
+        out = np.zeros((n, 8 if group == 1 else 16), dtype=np.uint64)
+        if n:
+            ctx.fixed_base_mul(group, g1_gen_mont() if group == 1 else g2_gen_mont(), scalars, n,
+                               out)
+        return out
+    return mul
+
+
+class Prover:
+    """Device-resident (constraint system, proving key) pair; ``prove`` = one zkmi_prove_batch."""
+
+    def __init__(self, ctx: _lib.Context, cc: CompiledCircuit, pk: ProvingKey,
+                 window_bits_g1: int = 0, window_bits_g2: int = 0):
+        self.ctx, self.cc, self.pk = ctx, cc, pk
+        self.n_inputs = cc.n_inputs
+        self._consts = to_mont_array(cc.consts) if cc.consts else np.zeros((0, 4), np.uint64)
+        prog = self._prog = np.ascontiguousarray(cc.program, dtype=np.uint32)
+        cd = _lib.CsDesc(cc.n_wires, cc.n_public, cc.n_secret, cc.n_constraints, cc.n_slots,
+                         cc.n_ops, len(cc.consts), 0, prog.ctypes.data, self._consts.ctypes.data)
+        self.cs_h = ctx.cs_load(cd)
+        self._keep = [np.ascontiguousarray(x) for x in
+                      (pk.a_wire, pk.b_wire, pk.k_wire, pk.g1_a, pk.g1_b, pk.g1_k, pk.g1_z, pk.g2_b,
+                       pk.g1_alpha, pk.g1_beta, pk.g1_delta, pk.g2_beta, pk.g2_delta)]
+        k = self._keep
+        pd = _lib.PkDesc(pk.log_n, pk.n_wires, len(pk.a_wire), len(pk.b_wire), len(pk.k_wire),
+                         pk.g1_z.shape[0], *[x.ctypes.data for x in k], window_bits_g1,
+                         window_bits_g2)
+        self.pk_h = ctx.pk_load(pd)
+
+    def close(self):
+        if getattr(self, "pk_h", None):
+            self.ctx.pk_free(self.pk_h)
+            self.pk_h = None
+        if getattr(self, "cs_h", None):
+            self.ctx.cs_free(self.cs_h)
+            self.cs_h = None
+
+    def solve(self, inputs, want_wires=True, want_abc=False):
+        """Witness solve only (cs.R1CS.Solve).  inputs: [batch, n_inputs, 4] Montgomery."""
+        batch = inputs.shape[0]
+        wires = np.zeros((batch, self.cc.n_wires, 4), np.uint64) if want_wires else None
+        abc = np.zeros((3, batch, self.cc.n_constraints, 4), np.uint64) if want_abc else None
+        status = self.ctx.solve_batch(self.cs_h, np.ascontiguousarray(inputs), batch, wires, abc)
+        return status, wires, abc
+
+    def prove(self, inputs, rs, proofs_out=None, status_out=None):
+        """inputs: [batch, n_inputs, 4] (numpy) or a device tensor; rs: [batch, 2, 4].
+        Returns (proofs [batch, 32] uint64: Ar | Krs | Bs, status [batch] int32)."""
+        batch = inputs.shape[0]
+        if proofs_out is None:
+            proofs_out = np.zeros((batch, 32), dtype=np.uint64)
+        if status_out is None:
+            status_out = np.zeros(batch, dtype=np.int32)
+        self.ctx.prove_batch(self.pk_h, self.cs_h, inputs, batch, rs, proofs_out, status_out)
+        return proofs_out, status_out

@@ -142,7 +142,8 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
 
 /* Per-stage device time of the last zkmi_prove_batch, milliseconds, measured with HIP events on
  * the context's stream: [0] solve, [1] quotient (NTTs + pointwise), [2] G1 MSMs, [3] G2 MSM,
- * [4] assembly, [5] total.  Also reports the MSM kernel's own launch count and time. */
+ * [4] assembly, [5] total, [6] sum over the four G1 msm_accumulate kernel launches alone (event
+ * pair around each launch), [7] the G2 msm_accumulate launch alone. */
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out /* 8 doubles */);
 
 #ifdef __cplusplus

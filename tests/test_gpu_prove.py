@@ -1,0 +1,126 @@
+"""GPU parity of witness solve and Groth16 prove (through the C-ABI) against the oracles.
+
+Bar: bit-exact.  Checker 1 = C oracle (gnark-style constraint-by-constraint solver, DIF/DIT NTT,
+Pippenger MSM); checker 2 = closed-form proof from the trapdoor (no NTT/MSM at all); checker 3 =
+pairing verification.  Prover-level results are pinned by nothing in the reference
+("parity unpinned"); see DESIGN.md §Oracle.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from gnark_crypto_primitives_amd import circuits, groth16
+from gnark_crypto_primitives_amd.frontend import compile_circuit
+from gnark_crypto_primitives_amd.frontend.compile import from_mont_array, to_mont_array
+from gnark_crypto_primitives_amd.tree import smt_witness
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _pts(proof):
+    def g1(a):
+        v = H.fq_unmont(a.reshape(-1, 4))
+        return None if not any(v) else (v[0], v[1])
+
+    def g2(a):
+        v = H.fq_unmont(a.reshape(-1, 4))
+        return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+    return g1(proof[0:8]), g1(proof[8:16]), g2(proof[16:32])
+
+
+@pytest.fixture(scope="module")
+def poseidon_setup(zk_ctx):
+    cc = compile_circuit(circuits.PoseidonCircuit())
+    pk, vk, td = groth16.setup(cc, 11, groth16.gpu_mul(zk_ctx))
+    prover = groth16.Prover(zk_ctx, cc, pk, window_bits_g1=8, window_bits_g2=6)
+    yield cc, pk, vk, td, prover
+    prover.close()
+
+
+def test_setup_matches_oracle(zk_ctx, poseidon_setup):
+    """GPU fixed-base setup == C-oracle setup on the same trapdoor."""
+    from oracle import cref
+    cc, pk, vk, td, _ = poseidon_setup
+    mul = lambda g, s: cref.batch_mul(g, H.g1_gen_mont() if g == 1 else H.g2_gen_mont(), s)
+    pk2, vk2, td2 = groth16.setup(cc, 11, mul)
+    assert td == td2
+    for name in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b", "g1_alpha", "g2_delta"):
+        assert np.array_equal(getattr(pk, name), getattr(pk2, name)), name
+    assert np.array_equal(vk.g1_k, vk2.g1_k)
+
+
+def test_poseidon_prove(zk_ctx, poseidon_setup):
+    from oracle import cref, pyref
+    cc, pk, vk, td, prover = poseidon_setup
+    rng = random.Random(3)
+    batch = 67
+    datas = [297262668938251460872476410954775437897592223497, 0, 1, pyref.R - 1] + \
+            [rng.randrange(pyref.R) for _ in range(batch - 4)]
+    inputs = [cc.assignment_vector({"Data": d, "Hash": pyref.poseidon_hash([d])}) for d in datas]
+    inp = np.stack([to_mont_array(v) for v in inputs])
+    rs_int = [(rng.randrange(pyref.R), rng.randrange(pyref.R)) for _ in range(batch)]
+    rs_int[1] = (0, 0)
+    rs = np.stack([to_mont_array(v) for v in rs_int])
+    # witness solve parity (wires and a, b, c)
+    status, wires, abc = prover.solve(inp, want_wires=True, want_abc=True)
+    assert not status.any()
+    rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
+    for i in (0, 1, 5, batch - 1):
+        rc, w, a, b, c = cref.r1cs_solve(rh, inp[i])
+        assert rc == 0
+        assert np.array_equal(wires[i], w)
+        assert np.array_equal(abc[0, i], a) and np.array_equal(abc[1, i], b)
+        assert np.array_equal(abc[2, i], c)
+    # prove parity, every proof
+    proofs, status = prover.prove(inp, rs)
+    assert not status.any()
+    want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp, rs)
+    assert not wstatus.any()
+    assert np.array_equal(proofs, want)
+    # closed form + pairing on two of them
+    vkd = dict(alpha=_pts(np.concatenate([vk.g1_alpha, vk.g1_alpha, vk.g2_beta]))[0],
+               beta=_pts(np.concatenate([vk.g1_alpha, vk.g1_alpha, vk.g2_beta]))[2],
+               gamma=_pts(np.concatenate([vk.g1_alpha, vk.g1_alpha, vk.g2_gamma]))[2],
+               delta=_pts(np.concatenate([vk.g1_alpha, vk.g1_alpha, vk.g2_delta]))[2],
+               k=[_pts(np.concatenate([k, k, vk.g2_beta]))[0] for k in vk.g1_k])
+    for i in (0, 1):
+        w_int = from_mont_array(wires[i])
+        exp = pyref.expected_proof(cc.constraints, cc.n_wires, cc.n_public, w_int, td, pk.log_n,
+                                   *rs_int[i])
+        assert _pts(proofs[i]) == exp
+        assert pyref.verify(vkd, w_int[:cc.n_public], _pts(proofs[i]))
+
+
+def test_invalid_witness_status(zk_ctx, poseidon_setup):
+    cc, pk, vk, td, prover = poseidon_setup
+    from oracle import pyref
+    good = cc.assignment_vector({"Data": 5, "Hash": pyref.poseidon_hash([5])})
+    bad = cc.assignment_vector({"Data": 5, "Hash": 7})
+    inp = np.stack([to_mont_array(good), to_mont_array(bad), to_mont_array(good)])
+    rs = np.stack([to_mont_array([1, 2])] * 3)
+    proofs, status = prover.prove(inp, rs)
+    assert list(status) == [0, -5, 0]
+    assert np.array_equal(proofs[0], proofs[2])
+
+
+@pytest.mark.parametrize("levels,populated", [(8, 3), (24, 0)])
+def test_smt_inclusion_prove(zk_ctx, levels, populated):
+    from oracle import cref
+    cc = compile_circuit(circuits.smt_inclusion_circuit(levels))
+    pk, vk, td = groth16.setup(cc, 5, groth16.gpu_mul(zk_ctx))
+    prover = groth16.Prover(zk_ctx, cc, pk, window_bits_g1=7, window_bits_g2=5)
+    rng = random.Random(levels)
+    batch = 9
+    ws = [smt_witness.synthetic_inclusion(rng, levels, populated) for _ in range(batch)]
+    ws[2]["Root"] = (ws[2]["Root"] + 1) % H.R          # wrong root -> unsatisfied
+    inp = np.stack([to_mont_array(cc.assignment_vector(w)) for w in ws])
+    rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in range(batch)])
+    proofs, status = prover.prove(inp, rs)
+    rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
+    want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp, rs)
+    assert list(status != 0) == list(wstatus != 0) == [i == 2 for i in range(batch)]
+    ok = status == 0
+    assert np.array_equal(proofs[ok], want[ok])
+    prover.close()
