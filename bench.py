@@ -22,6 +22,25 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def available_cpus():
+    """Host threads this process may really use: affinity mask, cgroup quota, and the GPU box's
+    documented per-GPU CPU share (16) as a ceiling; ZKMI_CPU_THREADS overrides."""
+    if os.environ.get("ZKMI_CPU_THREADS"):
+        return int(os.environ["ZKMI_CPU_THREADS"])
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +146,7 @@ def main():
         cpu = None
         if args.cpu_sample != 0:
             from oracle import cref
-            cores = os.cpu_count() or 1
+            cores = available_cpus()
             S = args.cpu_sample if args.cpu_sample > 0 else min(B, 2 * cores)
             rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
             tc = time.perf_counter()

@@ -1,0 +1,45 @@
+"""The C-ABI library loads and exports every symbol include/zkmi.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+from gnark_crypto_primitives_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "zkmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 20
+    handle = lib.load()
+    bound = {n for n, _, _ in lib.SYMBOLS}
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in zkmi.h but missing from libzkmi.so"
+        assert n in bound, f"{n} declared in zkmi.h but not bound in lib.py"
+    assert bound <= set(names)
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(lib.PkDesc) == 6 * 4 + 13 * 8 + 2 * 4
+    assert C.sizeof(lib.CsDesc) == 8 * 4 + 2 * 8
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a HIP device zkmi_init must refuse (ZKMI_ERR_NO_DEVICE), not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    handle = lib.load()
+    h = C.c_void_p()
+    assert handle.zkmi_init(0, C.byref(h)) == -3
+    try:
+        lib.Context(0)
+        raise AssertionError("Context() succeeded without a GPU")
+    except lib.ZkmiError:
+        pass
