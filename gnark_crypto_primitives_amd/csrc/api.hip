@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "zkmi_internal.h"
+#include "ff29.h"
 
 using namespace zk;
 
@@ -109,6 +110,18 @@ __global__ __launch_bounds__(256) void field_mul_bench_kernel(Fp<P>* io, int ite
     y = mul(y, x);
   }
   io[i] = add(x, y);
+}
+
+// the same measurement for the 9 x 29-bit representation used inside the G1 MSM (ff29.h)
+__global__ __launch_bounds__(256) void field_mul_bench_f29_kernel(Fq* io, int iters) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fq29 x = unpack29<Fq29Params>(io[i].v), y = x;
+  y.v[0] ^= 1;
+  for (int k = 0; k < iters; k++) {
+    x = mul(x, y);
+    y = mul(y, x);
+  }
+  pack_canonical<Fq29Params>(io[i].v, norm(add(x, y)));
 }
 
 // ---- proof assembly ---------------------------------------------------------------------------------
@@ -265,6 +278,9 @@ int zkmi_field_mul_bench(zkmi_ctx* ctx, int which, size_t n_threads, int iters, 
     if (which == 0)
       hipLaunchKernelGGL((field_mul_bench_kernel<FrParams>), dim3((unsigned)(n_threads / 256)),
                          dim3(256), 0, ctx->stream, (Fr*)buf, iters);
+    else if (which == 2)
+      hipLaunchKernelGGL(field_mul_bench_f29_kernel, dim3((unsigned)(n_threads / 256)), dim3(256),
+                         0, ctx->stream, (Fq*)buf, iters);
     else
       hipLaunchKernelGGL((field_mul_bench_kernel<FqParams>), dim3((unsigned)(n_threads / 256)),
                          dim3(256), 0, ctx->stream, (Fq*)buf, iters);

@@ -1,0 +1,77 @@
+// G1 mixed addition on the 9 x 29-bit lazy representation (ff29.h) for the MSM inner loop.
+// Same formulas as ec.h (EFD madd-2008-s / mdbl-2008-s-1); the comments track the limb and value
+// bounds that ff29.h's mul/sqr contracts need.
+#pragma once
+#include "ec.h"
+#include "ff29.h"
+
+namespace zk {
+
+// Invariants between calls: x, y normalised with |x| < 5p, |y| < 2p; zz, zzz mul outputs.
+struct G1Acc29 {
+  Fq29 x, y, zz, zzz;
+  bool inf;
+  static ZK_HD G1Acc29 infinity() {
+    G1Acc29 a;
+    a.x = a.y = a.zz = a.zzz = Fq29::zero();
+    a.inf = true;
+    return a;
+  }
+};
+
+// 2 * (qx, qy), affine input with |limbs| < 2^29
+ZK_HD void mdbl29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
+  const Fq29 u = norm(add(qy, qy));
+  const Fq29 v = sqr(u);
+  const Fq29 w = mul(u, v);
+  const Fq29 s = mul(qx, v);
+  const Fq29 x2 = sqr(qx);
+  const Fq29 m = norm(add(add(x2, x2), x2));
+  const Fq29 x3 = norm(sub(sqr(m), add(s, s)));
+  const Fq29 y3 = norm(sub(mul(m, sub(s, x3)), mul(w, qy)));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = v;
+  acc.zzz = w;
+  acc.inf = false;
+}
+
+// acc += (qx, qy); the addend is a finite point, canonical x in [0,p), y possibly negated
+// limb-wise (|limbs| < 2^29).
+ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
+  if (acc.inf) {
+    acc.x = qx;
+    acc.y = norm(qy);
+    acc.zz = acc.zzz = Fq29::one();
+    acc.inf = false;
+    return;
+  }
+  const Fq29 u2 = mul(qx, acc.zz);
+  const Fq29 s2 = mul(qy, acc.zzz);
+  const Fq29 p = sub(u2, acc.x);  // |limbs| < 2^29, |value| < 6.5p
+  const Fq29 r = sub(s2, acc.y);  // |value| < 3.5p
+  const Fq29 pp = sqr(p);
+  const Fq29 rr = sqr(r);
+  if (is_zero_mulout(pp)) {  // same x: doubling or cancellation (never on honest random data)
+    if (is_zero_mulout(rr))
+      mdbl29(acc, qx, qy);
+    else
+      acc.inf = true;
+    return;
+  }
+  const Fq29 ppp = mul(p, pp);
+  const Fq29 q = mul(acc.x, pp);
+  const Fq29 x3 = norm(sub(sub(rr, ppp), add(q, q)));             // (-5p, 3p)
+  const Fq29 y3 = norm(sub(mul(r, sub(q, x3)), mul(acc.y, ppp)));  // (-2p, 2p)
+  acc.zz = mul(acc.zz, pp);
+  acc.zzz = mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+}
+
+ZK_HD G1XYZZ to_std(const G1Acc29& a) {
+  if (a.inf) return G1XYZZ::inf();
+  return G1XYZZ{to_std(a.x), to_std(a.y), to_std(a.zz), to_std(a.zzz)};
+}
+
+}  // namespace zk

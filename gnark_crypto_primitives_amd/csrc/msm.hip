@@ -23,8 +23,17 @@
 //
 // Algorithmic bytes per launch: n * sizeof(affine) + batch * n * 32.
 #include "zkmi_internal.h"
+#include "ec29.h"
 
 namespace zk {
+
+ZK_HD Fq to_r261_domain(const Fq& x) {
+  Fq k;
+#pragma unroll
+  for (int i = 0; i < 8; i++) k.v[i] = Fq29Params::k261(i);
+  return mul(x, k);
+}
+ZK_HD Fq2 to_r261_domain(const Fq2& x) { return x; }  // G2 tables stay in the standard domain
 
 // ---- table construction ------------------------------------------------------------------------
 // One thread per base, windows in sequence.  Per window: D = 2^(c-1) running mixed additions into
@@ -34,7 +43,8 @@ template <class F>
 __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restrict__ bases,
                                                       uint32_t i0, uint32_t n, int c, int W,
                                                       Affine<F>* __restrict__ table,
-                                                      F* __restrict__ scratch, uint32_t T) {
+                                                      F* __restrict__ scratch, uint32_t T,
+                                                      int to_r261) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = i0 + t;
   if (t >= T || i >= n) return;
@@ -70,6 +80,14 @@ __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restric
       row[d].y = mul(row[d].y, izzz);
     }
     if (j + 1 < W) Q = to_affine(dbl_affine(row[D - 1]));
+    // G1 tables feed msm_accumulate_g1_f29: store x*2^261, y*2^261 (canonical) instead of the
+    // R = 2^256 Montgomery image, so the inner loop only unpacks limbs
+    if (to_r261) {
+      for (uint32_t d = 0; d < D; d++) {
+        row[d].x = to_r261_domain(row[d].x);
+        row[d].y = to_r261_domain(row[d].y);
+      }
+    }
   }
 }
 
@@ -111,6 +129,45 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
     }
   }
   partial[(size_t)chunk * Bp + b] = acc;
+}
+
+// G1 specialisation on the 9 x 29-bit lazy representation (ff29.h / ec29.h): same walk, the
+// accumulator lives in 36 VGPRs, every field product is a carry-free v_mad_i64_i32 chain.
+__global__ __launch_bounds__(256) void msm_accumulate_g1_f29(const G1Affine* __restrict__ table,
+                                                             const Fr* __restrict__ scalars,
+                                                             const uint32_t* __restrict__ row_idx,
+                                                             size_t Bp, uint32_t n,
+                                                             uint32_t per_chunk, int c, int W,
+                                                             G1XYZZ* __restrict__ partial) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y;
+  const uint32_t i0 = chunk * per_chunk;
+  uint32_t i1 = i0 + per_chunk;
+  if (i1 > n) i1 = n;
+  const uint32_t mask = (1u << c) - 1u;
+  const uint32_t half = 1u << (c - 1);
+  G1Acc29 acc = G1Acc29::infinity();
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t row = row_idx ? row_idx[i] : i;
+    Fr s = from_mont(scalars[(size_t)row * Bp + b]);
+    if (s.is_zero()) continue;
+    const G1Affine* trow = table + (((size_t)i * W) << (c - 1));
+    uint32_t carry = 0;
+    for (int j = 0; j < W; j++) {
+      uint32_t d = (s.v[0] & mask) + carry;
+#pragma unroll
+      for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> c) | (s.v[l + 1] << (32 - c));
+      s.v[7] >>= c;
+      const bool negd = d > half;
+      carry = negd ? 1u : 0u;
+      const uint32_t mag = negd ? (mask + 1u - d) : d;
+      if (mag) {
+        const G1Affine e = trow[((size_t)j << (c - 1)) + (mag - 1)];
+        madd29(acc, unpack29<Fq29Params>(e.x.v), cneg(unpack29<Fq29Params>(e.y.v), negd));
+      }
+    }
+  }
+  partial[(size_t)chunk * Bp + b] = to_std(acc);
 }
 
 template <class F>
@@ -167,7 +224,7 @@ static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c
   for (size_t i0 = 0; i0 < n; i0 += T) {
     hipLaunchKernelGGL((msm_build_table<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
                        bases_dev, (uint32_t)i0, (uint32_t)n, c, W, table, (F*)scratch,
-                       (uint32_t)T);
+                       (uint32_t)T, (int)(sizeof(F) == sizeof(Fq)));
   }
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -235,9 +292,14 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     ctx->msm_ev_group[ev] = bases->group;
     hipEventRecord(ctx->msm_ev[ev][0], ctx->stream);
   }
-  hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx), 0,
-                     ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
-                     (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  if constexpr (sizeof(F) == sizeof(Fq))
+    hipLaunchKernelGGL(msm_accumulate_g1_f29, dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx),
+                       0, ctx->stream, (const G1Affine*)bases->table, scalars, row_idx, Bp,
+                       (uint32_t)n, per_chunk, bases->c, bases->n_windows, (G1XYZZ*)partial);
+  else
+    hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx),
+                       0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
+                       (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
   if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
   hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
                      (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, out);

@@ -53,7 +53,8 @@ void* zkmi_stream(zkmi_ctx* ctx);
 /* r[i] = a[i] * b[i] in fr (which = 0) or fp (which = 1).   stands in for fr.Element.Mul / fp.Element.Mul */
 int zkmi_field_mul(zkmi_ctx* ctx, int which, const void* a, const void* b, void* r, size_t n);
 /* Throughput microbenchmark: every lane runs `iters` dependent Montgomery products; returns
- * products per second in *rate (integer-ALU roofline measurement). */
+ * products per second in *rate (integer-ALU roofline measurement).  which: 0 = fr,
+ * 1 = fp (8 x 32-bit limbs, ff.h), 2 = fp in the 9 x 29-bit form the G1 MSM uses (ff29.h). */
 int zkmi_field_mul_bench(zkmi_ctx* ctx, int which, size_t n_threads, int iters, double* rate);
 
 /* Batched NTT over fr, natural order in and out, in place.  stands in for

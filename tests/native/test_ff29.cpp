@@ -1,0 +1,95 @@
+// Host-side unit test of csrc/ff29.h + ec29.h against csrc/ff.h + ec.h (same code the GPU runs).
+//   g++ -O2 -std=c++17 -I gnark_crypto_primitives_amd/csrc tests/native/test_ff29.cpp -o /tmp/t && /tmp/t
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "ec29.h"
+
+using namespace zk;
+
+static std::mt19937_64 rng(12345);
+static Fq rand_fq() {
+  Fq x;
+  for (int i = 0; i < 8; i++) x.v[i] = (uint32_t)rng();
+  x.v[7] &= 0x0fffffffu;  // < 2^252 < p
+  return x;
+}
+static int fails = 0;
+#define CHECK(c)                                            \
+  do {                                                      \
+    if (!(c)) {                                             \
+      printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c);    \
+      fails++;                                              \
+    }                                                       \
+  } while (0)
+
+int main() {
+  // field: round trip, mul, sqr, add/sub chains
+  for (int it = 0; it < 20000; it++) {
+    Fq x = rand_fq(), y = rand_fq(), z = rand_fq();
+    if (it == 0) x = Fq::zero();
+    if (it == 1) { x = Fq::zero(); y = Fq::zero(); }
+    if (it == 2) for (int i = 0; i < 8; i++) x.v[i] = FqParams::p(i) - (i == 0 ? 1 : 0);  // p-1
+    Fq29 X = from_std<Fq29Params>(x), Y = from_std<Fq29Params>(y), Z = from_std<Fq29Params>(z);
+    CHECK(to_std(X) == x);
+    CHECK(to_std(mul(X, Y)) == mul(x, y));
+    CHECK(to_std(sqr(X)) == sqr(x));
+    // lazy combos: (x - y) * (z - x), one operand a 3-term sum normalised
+    CHECK(to_std(mul(sub(X, Y), sub(Z, X))) == mul(sub(x, y), sub(z, x)));
+    CHECK(to_std(sqr(sub(X, Y))) == sqr(sub(x, y)));
+    Fq29 T = norm(sub(sub(X, Y), add(Z, Z)));
+    CHECK(to_std(mul(T, sub(Y, Z))) == mul(sub(sub(x, y), dbl(z)), sub(y, z)));
+    CHECK(to_std(neg(X)) == neg(x));
+    CHECK(is_zero_mulout(mul(sub(X, X), Y)));
+    CHECK(is_zero_mulout(sqr(sub(X, Y))) == (x == y));
+  }
+  // curve: random walk of mixed additions incl. doubling / cancellation / infinity
+  G1Affine g{Fq::one(), dbl(Fq::one())};  // (1, 2)
+  // a few multiples of g as affine points
+  G1Affine pts[16];
+  {
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int i = 0; i < 16; i++) {
+      madd(acc, g);
+      if (i % 3 == 2) acc = dbl(acc);
+      pts[i] = to_affine(acc);
+    }
+  }
+  for (int trial = 0; trial < 200; trial++) {
+    G1XYZZ ref = G1XYZZ::inf();
+    G1Acc29 acc = G1Acc29::infinity();
+    for (int step = 0; step < 40; step++) {
+      int k = (int)(rng() % 16);
+      bool negd = rng() & 1;
+      if (trial % 7 == 0 && step == 1) { k = k; }  // free
+      G1Affine q = pts[k];
+      if (trial % 5 == 0 && step == 1) {           // force doubling: add the current sum again
+        q = to_affine(ref);
+        negd = false;
+        if (q.is_inf()) continue;
+      }
+      if (trial % 5 == 1 && step == 3) {           // force cancellation
+        q = to_affine(ref);
+        negd = true;
+        if (q.is_inf()) continue;
+      }
+      G1Affine qs = q;
+      if (negd) qs.y = neg(q.y);
+      madd(ref, qs);
+      // table entries are canonical values in the 2^261 domain
+      Fq kx = mul(q.x, Fq{{Fq29Params::k261(0), Fq29Params::k261(1), Fq29Params::k261(2),
+                           Fq29Params::k261(3), Fq29Params::k261(4), Fq29Params::k261(5),
+                           Fq29Params::k261(6), Fq29Params::k261(7)}});
+      Fq ky = mul(q.y, Fq{{Fq29Params::k261(0), Fq29Params::k261(1), Fq29Params::k261(2),
+                           Fq29Params::k261(3), Fq29Params::k261(4), Fq29Params::k261(5),
+                           Fq29Params::k261(6), Fq29Params::k261(7)}});
+      Fq29 X = unpack29<Fq29Params>(kx.v), Y = cneg(unpack29<Fq29Params>(ky.v), negd);
+      madd29(acc, X, Y);
+      G1Affine a1 = to_affine(ref), a2 = to_affine(to_std(acc));
+      CHECK(a1.x == a2.x && a1.y == a2.y);
+    }
+  }
+  printf(fails ? "ff29 tests FAILED (%d)\n" : "ff29 tests ok\n", fails);
+  return fails != 0;
+}
