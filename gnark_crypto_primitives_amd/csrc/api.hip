@@ -520,6 +520,18 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
         ok = dst < d->n_slots && a < d->n_slots && b < d->n_slots;
         n_abc++;
         break;
+      case OP_BATCHINV: {
+        // dst = number of (OP_PAIR, dst, src) rows that follow; distinct wire slots on both sides
+        ok = (uint64_t)i + dst < d->n_ops;
+        for (uint32_t k = 1; ok && k <= dst; k++) {
+          const uint32_t* q = p + 4 * (size_t)(i + k);
+          ok = (q[0] & 0xff) == OP_PAIR && q[1] < d->n_wires && q[2] < d->n_wires && q[1] != q[2];
+          for (uint32_t k2 = 1; ok && k2 <= dst; k2++)
+            ok = q[1] != p[4 * (size_t)(i + k2) + 2];   // no dst aliases any src
+        }
+        if (ok) i += dst;
+        break;
+      }
       default:
         ok = false;
     }

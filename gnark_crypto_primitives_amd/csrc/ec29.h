@@ -69,6 +69,72 @@ ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
   acc.y = y3;
 }
 
+// ---- G2 (Fq2 components, lazy reduction) -------------------------------------------------------
+// Invariants between calls: x, y weakly reduced (|component| < 0.6p); zz, zzz products.
+struct G2Acc29 {
+  Fq2_29 x, y, zz, zzz;
+  bool inf;
+  static ZK_HD G2Acc29 infinity() {
+    G2Acc29 a;
+    a.x = a.y = a.zz = a.zzz = Fq2_29::zero();
+    a.inf = true;
+    return a;
+  }
+};
+
+ZK_HD void mdbl29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
+  const Fq2_29 u = norm(add(qy, qy));
+  const Fq2_29 v = sqr(u);
+  const Fq2_29 w = mul(u, v);
+  const Fq2_29 s = mul(qx, v);
+  const Fq2_29 x2 = sqr(qx);
+  const Fq2_29 m = norm(add(add(x2, x2), x2));
+  const Fq2_29 x3 = wred(sub(sqr(m), add(s, s)));
+  const Fq2_29 y3 = wred(sub(mul(m, sub(s, x3)), mul(w, qy)));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = v;
+  acc.zzz = w;
+  acc.inf = false;
+}
+
+// qx canonical components, qy canonical or limb-wise negated
+ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
+  if (acc.inf) {
+    acc.x = qx;
+    acc.y = norm(qy);
+    acc.zz = acc.zzz = Fq2_29::one();
+    acc.inf = false;
+    return;
+  }
+  const Fq2_29 u2 = mul(qx, acc.zz);
+  const Fq2_29 s2 = mul(qy, acc.zzz);
+  const Fq2_29 p = sub(u2, acc.x);  // |component| < 1.7p, |limb| < 2^29
+  const Fq2_29 r = sub(s2, acc.y);
+  const Fq2_29 pp = sqr(p);
+  const Fq2_29 rr = sqr(r);
+  if (is_zero_mulout(pp)) {
+    if (is_zero_mulout(rr))
+      mdbl29(acc, qx, qy);
+    else
+      acc.inf = true;
+    return;
+  }
+  const Fq2_29 ppp = mul(p, pp);
+  const Fq2_29 q = mul(acc.x, pp);
+  const Fq2_29 x3 = wred(sub(sub(rr, ppp), add(q, q)));
+  const Fq2_29 y3 = wred(sub(mul(r, sub(q, x3)), mul(acc.y, ppp)));
+  acc.zz = mul(acc.zz, pp);
+  acc.zzz = mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+}
+
+ZK_HD G2XYZZ to_std(const G2Acc29& a) {
+  if (a.inf) return G2XYZZ::inf();
+  return G2XYZZ{to_std(a.x), to_std(a.y), to_std(a.zz), to_std(a.zzz)};
+}
+
 ZK_HD G1XYZZ to_std(const G1Acc29& a) {
   if (a.inf) return G1XYZZ::inf();
   return G1XYZZ{to_std(a.x), to_std(a.y), to_std(a.zz), to_std(a.zzz)};

@@ -261,6 +261,88 @@ ZK_HD Fp<typename P::Std> to_std(const F29<P>& a) {
   return r;
 }
 
+// (a*b + c*d) / 2^261: two products share one Montgomery reduction ("lazy reduction").
+// Column bound: 18 + 9 partial products below 2^58 each -> all four operands need |limb| < 2^29.
+// |a*b + c*d| < 64 p^2.  Result normalised, value in (-p/2, 3p/2).
+template <class P>
+ZK_HD F29<P> mul_add2(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+  int64_t acc = 0;
+  int32_t m[9];
+  F29<P> r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      acc += (int64_t)a.v[i] * b.v[k - i];
+      acc += (int64_t)c.v[i] * d.v[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P::p(k - i);
+    m[k] = (int32_t)(((uint32_t)acc * P::inv) & (uint32_t)F29<P>::MASK);
+    acc += (int64_t)m[k] * P::p(0);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) {
+      acc += (int64_t)a.v[i] * b.v[k - i];
+      acc += (int64_t)c.v[i] * d.v[k - i];
+    }
+#pragma unroll
+    for (int i = k - 8; i < 9; i++) acc += (int64_t)m[i] * P::p(k - i);
+    r.v[k - 9] = (int32_t)acc & F29<P>::MASK;
+    acc >>= 29;
+  }
+  r.v[8] = (int32_t)acc;
+  return r;
+}
+
+// weak reduction of a value with |v| < 2^7 p (limbs below 2^31 in magnitude): subtract the
+// multiple of p estimated from the top limb; result normalised with |v| < 0.6 p.
+template <class P>
+ZK_HD F29<P> wred(const F29<P>& a) {
+  const F29<P> v = norm(a);
+  const float ptop = (float)P::p(8) + 0.5f;
+  const int32_t q = (int32_t)__builtin_rintf((float)v.v[8] / ptop);
+  F29<P> r;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)v.v[i] - (int64_t)q * P::p(i);
+    r.v[i] = (int32_t)c & F29<P>::MASK;
+    c >>= 29;
+  }
+  r.v[8] = (int32_t)(c + (int64_t)v.v[8] - (int64_t)q * P::p(8));
+  return r;
+}
+
 typedef F29<Fq29Params> Fq29;
+
+// ---- Fq2 = Fq[u]/(u^2+1) on the lazy representation -----------------------------------------
+// Components are kept normalised; products use one shared reduction per component.
+struct Fq2_29 {
+  Fq29 c0, c1;
+  static ZK_HD Fq2_29 one() { return Fq2_29{Fq29::one(), Fq29::zero()}; }
+  static ZK_HD Fq2_29 zero() { return Fq2_29{Fq29::zero(), Fq29::zero()}; }
+};
+ZK_HD Fq2_29 add(const Fq2_29& a, const Fq2_29& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+ZK_HD Fq2_29 sub(const Fq2_29& a, const Fq2_29& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+ZK_HD Fq2_29 cneg(const Fq2_29& a, bool c) { return {cneg(a.c0, c), cneg(a.c1, c)}; }
+ZK_HD Fq2_29 norm(const Fq2_29& a) { return {norm(a.c0), norm(a.c1)}; }
+ZK_HD Fq2_29 wred(const Fq2_29& a) { return {wred(a.c0), wred(a.c1)}; }
+// operands: |limb| < 2^29 (normalised values or differences of two)
+ZK_HD Fq2_29 mul(const Fq2_29& a, const Fq2_29& b) {
+  return {mul_add2(a.c0, b.c0, neg(a.c1), b.c1), mul_add2(a.c0, b.c1, a.c1, b.c0)};
+}
+ZK_HD Fq2_29 sqr(const Fq2_29& a) {
+  // (a0+a1)(a0-a1) + 2 a0 a1 u ; the sum is the one operand allowed |limb| < 2^30
+  return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(add(a.c0, a.c0), a.c1)};
+}
+ZK_HD bool is_zero_mulout(const Fq2_29& a) { return is_zero_mulout(a.c0) && is_zero_mulout(a.c1); }
+ZK_HD Fq2 to_std(const Fq2_29& a) { return Fq2{to_std(a.c0), to_std(a.c1)}; }
+ZK_HD Fq2_29 unpack2_29(const Fq2& x) {
+  return {unpack29<Fq29Params>(x.c0.v), unpack29<Fq29Params>(x.c1.v)};
+}
 
 }  // namespace zk

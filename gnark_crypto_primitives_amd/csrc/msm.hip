@@ -33,7 +33,7 @@ ZK_HD Fq to_r261_domain(const Fq& x) {
   for (int i = 0; i < 8; i++) k.v[i] = Fq29Params::k261(i);
   return mul(x, k);
 }
-ZK_HD Fq2 to_r261_domain(const Fq2& x) { return x; }  // G2 tables stay in the standard domain
+ZK_HD Fq2 to_r261_domain(const Fq2& x) { return Fq2{to_r261_domain(x.c0), to_r261_domain(x.c1)}; }
 
 // ---- table construction ------------------------------------------------------------------------
 // One thread per base, windows in sequence.  Per window: D = 2^(c-1) running mixed additions into
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restric
       row[d].y = mul(row[d].y, izzz);
     }
     if (j + 1 < W) Q = to_affine(dbl_affine(row[D - 1]));
-    // G1 tables feed msm_accumulate_g1_f29: store x*2^261, y*2^261 (canonical) instead of the
+    // the tables feed msm_accumulate_f29: store x*2^261, y*2^261 (canonical) instead of the
     // R = 2^256 Montgomery image, so the inner loop only unpacks limbs
     if (to_r261) {
       for (uint32_t d = 0; d < D; d++) {
@@ -92,7 +92,23 @@ __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restric
 }
 
 // ---- accumulation --------------------------------------------------------------------------------
-// grid: x over proofs (Bp / blockDim.x), y over chunks of bases.  c, W uniform.
+// grid: x over proofs (Bp / blockDim.x), y over chunks of bases.  c, W wave-uniform.
+// The accumulator lives in the 9 x 29-bit lazy representation (ff29.h / ec29.h): every field
+// product is a carry-free v_mad_i64_i32 chain; G2 shares one Montgomery reduction per Fq2 component.
+template <class F> struct Acc29;
+template <> struct Acc29<Fq> {
+  typedef G1Acc29 type;
+  static __device__ __forceinline__ void add(G1Acc29& acc, const G1Affine& e, bool negd) {
+    madd29(acc, unpack29<Fq29Params>(e.x.v), cneg(unpack29<Fq29Params>(e.y.v), negd));
+  }
+};
+template <> struct Acc29<Fq2> {
+  typedef G2Acc29 type;
+  static __device__ __forceinline__ void add(G2Acc29& acc, const G2Affine& e, bool negd) {
+    madd29(acc, unpack2_29(e.x), cneg(unpack2_29(e.y), negd));
+  }
+};
+
 template <class F>
 __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restrict__ table,
                                                       const Fr* __restrict__ scalars,
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
   if (i1 > n) i1 = n;
   const uint32_t mask = (1u << c) - 1u;
   const uint32_t half = 1u << (c - 1);
-  XYZZ<F> acc = XYZZ<F>::inf();
+  typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t i = i0; i < i1; i++) {
     const uint32_t row = row_idx ? row_idx[i] : i;
     Fr s = from_mont(scalars[(size_t)row * Bp + b]);
@@ -122,48 +138,8 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
       carry = negd ? 1u : 0u;
       const uint32_t mag = negd ? (mask + 1u - d) : d;
       if (mag) {
-        Affine<F> p = trow[((size_t)j << (c - 1)) + (mag - 1)];
-        if (negd) p.y = neg(p.y);
-        madd(acc, p);
-      }
-    }
-  }
-  partial[(size_t)chunk * Bp + b] = acc;
-}
-
-// G1 specialisation on the 9 x 29-bit lazy representation (ff29.h / ec29.h): same walk, the
-// accumulator lives in 36 VGPRs, every field product is a carry-free v_mad_i64_i32 chain.
-__global__ __launch_bounds__(256) void msm_accumulate_g1_f29(const G1Affine* __restrict__ table,
-                                                             const Fr* __restrict__ scalars,
-                                                             const uint32_t* __restrict__ row_idx,
-                                                             size_t Bp, uint32_t n,
-                                                             uint32_t per_chunk, int c, int W,
-                                                             G1XYZZ* __restrict__ partial) {
-  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t chunk = blockIdx.y;
-  const uint32_t i0 = chunk * per_chunk;
-  uint32_t i1 = i0 + per_chunk;
-  if (i1 > n) i1 = n;
-  const uint32_t mask = (1u << c) - 1u;
-  const uint32_t half = 1u << (c - 1);
-  G1Acc29 acc = G1Acc29::infinity();
-  for (uint32_t i = i0; i < i1; i++) {
-    const uint32_t row = row_idx ? row_idx[i] : i;
-    Fr s = from_mont(scalars[(size_t)row * Bp + b]);
-    if (s.is_zero()) continue;
-    const G1Affine* trow = table + (((size_t)i * W) << (c - 1));
-    uint32_t carry = 0;
-    for (int j = 0; j < W; j++) {
-      uint32_t d = (s.v[0] & mask) + carry;
-#pragma unroll
-      for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> c) | (s.v[l + 1] << (32 - c));
-      s.v[7] >>= c;
-      const bool negd = d > half;
-      carry = negd ? 1u : 0u;
-      const uint32_t mag = negd ? (mask + 1u - d) : d;
-      if (mag) {
-        const G1Affine e = trow[((size_t)j << (c - 1)) + (mag - 1)];
-        madd29(acc, unpack29<Fq29Params>(e.x.v), cneg(unpack29<Fq29Params>(e.y.v), negd));
+        const Affine<F> e = trow[((size_t)j << (c - 1)) + (mag - 1)];
+        Acc29<F>::add(acc, e, negd);
       }
     }
   }
@@ -192,12 +168,12 @@ __global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __res
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 15 %
-// for its G2 bases (Arbo-160 on a 288 GB MI355X: c = 10 for G1, c = 9 for G2).
+// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 20 %
+// for its G2 bases (Arbo-160 on a 288 GB MI355X: c = 10 for both).
 int default_window(size_t n, int group) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  const double budget = (group == 1 ? 0.60 : 0.15) * (double)free_b;
+  const double budget = (group == 1 ? 0.60 : 0.20) * (double)free_b;
   const double entry = group == 1 ? 64.0 : 128.0;
   int best = 4;
   for (int c = 4; c <= 12; c++) {
@@ -224,7 +200,7 @@ static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c
   for (size_t i0 = 0; i0 < n; i0 += T) {
     hipLaunchKernelGGL((msm_build_table<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
                        bases_dev, (uint32_t)i0, (uint32_t)n, c, W, table, (F*)scratch,
-                       (uint32_t)T, (int)(sizeof(F) == sizeof(Fq)));
+                       (uint32_t)T, 1);
   }
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipStreamSynchronize(ctx->stream));
@@ -292,14 +268,9 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     ctx->msm_ev_group[ev] = bases->group;
     hipEventRecord(ctx->msm_ev[ev][0], ctx->stream);
   }
-  if constexpr (sizeof(F) == sizeof(Fq))
-    hipLaunchKernelGGL(msm_accumulate_g1_f29, dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx),
-                       0, ctx->stream, (const G1Affine*)bases->table, scalars, row_idx, Bp,
-                       (uint32_t)n, per_chunk, bases->c, bases->n_windows, (G1XYZZ*)partial);
-  else
-    hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx),
-                       0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
-                       (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx), 0,
+                     ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
+                     (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
   if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
   hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
                      (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, out);

@@ -74,6 +74,32 @@ __global__ __launch_bounds__(64) void solve_kernel(const uint4* __restrict__ pro
         }
         break;
       }
+      case OP_BATCHINV: {
+        // rows pc+1 .. pc+n are (OP_PAIR, dst, src): dst = 1/src (0 for 0) with one inversion.
+        // dst rows double as the prefix-product scratch; dst and src slots are distinct wires.
+        const uint32_t n = d;
+        Fr acc = Fr::one();
+        for (uint32_t k = 1; k <= n; k++) {
+          const uint4 pr = prog[pc + k];
+          const Fr v = SLOT(pr.z);
+          SLOT(pr.y) = acc;
+          if (!v.is_zero()) acc = mul(acc, v);
+        }
+        Fr inv = inverse(acc);
+        for (uint32_t k = n; k >= 1; k--) {
+          const uint4 pr = prog[pc + k];
+          const Fr v = SLOT(pr.z);
+          if (v.is_zero()) {
+            SLOT(pr.y) = Fr::zero();
+          } else {
+            const Fr res = mul(inv, SLOT(pr.y));
+            inv = mul(inv, v);
+            SLOT(pr.y) = res;
+          }
+        }
+        pc += n;
+        break;
+      }
       case OP_ABC: {
         const Fr va = SLOT(d), vb = SLOT(x), vc = SLOT(y);
         a[(size_t)k * Bp + lane] = va;

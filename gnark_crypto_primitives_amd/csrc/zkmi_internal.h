@@ -77,7 +77,7 @@ namespace zk {
 
 // witness-program opcodes (frontend/api.py)
 enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC,
-       OP_ABC, OP_COPY, OP_DIV };
+       OP_ABC, OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR };
 
 #define ZK_HIP(call)                                                         \
   do {                                                                       \

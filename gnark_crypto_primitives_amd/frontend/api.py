@@ -27,7 +27,7 @@ R = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 
 # witness-program opcodes (decoded by csrc/solve.hip and by CompiledCircuit.run_program)
 OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC, OP_ABC, \
-    OP_COPY, OP_DIV = range(13)
+    OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR = range(15)
 
 HINT_INVZERO, HINT_NBITS = 1, 2
 

@@ -13,8 +13,9 @@ import hashlib
 
 import numpy as np
 
-from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BITS, OP_COPY,
-                  OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULC, OP_NEG, OP_SETC, OP_SUB, R)
+from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS,
+                  OP_COPY, OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULC, OP_NEG, OP_PAIR, OP_SETC,
+                  OP_SUB, R)
 
 
 class _Field:
@@ -148,6 +149,16 @@ class CompiledCircuit:
                 elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY):
                     live[a] = True
         ops = [o for o, k in zip(ops, keep) if k]
+        # ---- inversions of input wires (e.g. the IsZero of every SMT sibling) are hoisted to the
+        # top and done with ONE field inversion (Montgomery's trick): OP_BATCHINV + (dst, src) rows
+        n_in_wires = 1 + self.n_inputs
+        hoist = [o for o in ops if o[0] == OP_INV and val_wire.get(o[2], n_in_wires) < n_in_wires
+                 and o[1] in val_wire]
+        if len(hoist) >= 4:
+            hs = set(id(o) for o in hoist)
+            ops = ([(OP_BATCHINV, len(hoist), 0, 0)] +
+                   [(OP_PAIR, o[1], o[2], 0) for o in hoist] +
+                   [o for o in ops if id(o) not in hs])
         # ---- last use of every value
         last = {}
         for i, (op, dst, a, b) in enumerate(ops):
@@ -155,7 +166,7 @@ class CompiledCircuit:
                 last[dst] = last[a] = last[b] = i
             elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
                 last[a] = last[b] = i
-            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
+            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS, OP_PAIR):
                 last[a] = i
         # ---- slot assignment: wire-backed values live in their wire's slot forever; the rest
         # share a pool of temporaries above n_wires, recycled after the last use
@@ -165,6 +176,12 @@ class CompiledCircuit:
         n_abc = 0
         for i, (op, dst, a, b) in enumerate(ops):
             srcs = ()
+            if op == OP_BATCHINV:
+                prog[i] = (op, dst, 0, 0)           # dst field = number of (dst, src) rows
+                continue
+            if op == OP_PAIR:
+                prog[i] = (op, slot[dst], slot[a], 0)   # both wire-backed, never recycled
+                continue
             if op == OP_ABC:
                 srcs = (dst, a, b)
                 # bit 8: the solver verifies this row (assertion / division)
@@ -241,6 +258,8 @@ class CompiledCircuit:
                     s[d + k] = (v >> k) & 1
             elif op == OP_COPY:
                 s[d] = s[a]
+            elif op == OP_PAIR:                      # row of a preceding OP_BATCHINV
+                s[d] = pow(s[a], R - 2, R)
             elif op == OP_END:
                 break
         return s[:self.n_wires], a_, b_, c_

@@ -90,6 +90,51 @@ int main() {
       CHECK(a1.x == a2.x && a1.y == a2.y);
     }
   }
+  // ---- Fq2 and G2 on the lazy representation
+  auto K = Fq{{Fq29Params::k261(0), Fq29Params::k261(1), Fq29Params::k261(2), Fq29Params::k261(3),
+               Fq29Params::k261(4), Fq29Params::k261(5), Fq29Params::k261(6), Fq29Params::k261(7)}};
+  for (int it = 0; it < 5000; it++) {
+    Fq2 x{rand_fq(), rand_fq()}, y{rand_fq(), rand_fq()}, z{rand_fq(), rand_fq()};
+    Fq2_29 X{from_std<Fq29Params>(x.c0), from_std<Fq29Params>(x.c1)};
+    Fq2_29 Y{from_std<Fq29Params>(y.c0), from_std<Fq29Params>(y.c1)};
+    Fq2_29 Z{from_std<Fq29Params>(z.c0), from_std<Fq29Params>(z.c1)};
+    CHECK(to_std(mul(X, Y)) == mul(x, y));
+    CHECK(to_std(sqr(X)) == sqr(x));
+    CHECK(to_std(mul(sub(X, Y), sub(Z, Y))) == mul(sub(x, y), sub(z, y)));
+    Fq2_29 T = wred(sub(sub(mul(X, Y), Z), add(X, X)));
+    CHECK(to_std(T) == sub(sub(mul(x, y), z), dbl(x)));
+    CHECK(to_std(sqr(sub(T, Y))) == sqr(sub(sub(sub(mul(x, y), z), dbl(x)), y)));
+  }
+  {
+    // G2 generator (plain integers -> Montgomery), then a walk like the G1 one
+    const Fq gx0 = to_mont(Fq{{0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu}}), gx1 = to_mont(Fq{{0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u}});
+    const Fq gy0 = to_mont(Fq{{0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u}}), gy1 = to_mont(Fq{{0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u}});
+    G2Affine g2{Fq2{gx0, gx1}, Fq2{gy0, gy1}};
+    G2Affine pts2[12];
+    G2XYZZ a0 = G2XYZZ::inf();
+    for (int i = 0; i < 12; i++) {
+      madd(a0, g2);
+      if (i % 4 == 3) a0 = dbl(a0);
+      pts2[i] = to_affine(a0);
+    }
+    for (int trial = 0; trial < 60; trial++) {
+      G2XYZZ ref = G2XYZZ::inf();
+      G2Acc29 acc = G2Acc29::infinity();
+      for (int step = 0; step < 30; step++) {
+        G2Affine q = pts2[rng() % 12];
+        bool negd = rng() & 1;
+        if (trial % 5 == 0 && step == 2) { q = to_affine(ref); negd = false; if (q.is_inf()) continue; }
+        if (trial % 5 == 1 && step == 4) { q = to_affine(ref); negd = true; if (q.is_inf()) continue; }
+        G2Affine qs = q;
+        if (negd) qs.y = neg(q.y);
+        madd(ref, qs);
+        Fq2 kx{mul(q.x.c0, K), mul(q.x.c1, K)}, ky{mul(q.y.c0, K), mul(q.y.c1, K)};
+        madd29(acc, unpack2_29(kx), cneg(unpack2_29(ky), negd));
+        G2Affine r1 = to_affine(ref), r2 = to_affine(to_std(acc));
+        CHECK(r1.x == r2.x && r1.y == r2.y);
+      }
+    }
+  }
   printf(fails ? "ff29 tests FAILED (%d)\n" : "ff29 tests ok\n", fails);
   return fails != 0;
 }
