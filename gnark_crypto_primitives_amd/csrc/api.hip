@@ -125,65 +125,74 @@ __global__ __launch_bounds__(256) void field_mul_bench_f29_kernel(Fq* io, int it
 }
 
 // ---- proof assembly ---------------------------------------------------------------------------------
-// One lane per proof.  Ar = sumA + alpha + r*delta ; Bs1 = sumB1 + beta + s*delta ;
-// Bs = sumB2 + beta2 + s*delta2 ; Krs = sumK + sumZ - rs*delta + s*Ar + r*Bs1.
+// Ar = sumA + alpha + r*delta ; Bs1 = sumB1 + beta + s*delta ; Bs = sumB2 + beta2 + s*delta2 ;
+// Krs = sumK + sumZ - rs*delta + s*Ar + r*Bs1.
+// The multiples of the fixed points delta / delta2 come from one-base window tables through the
+// MSM kernel itself (26-32 mixed additions instead of a 254-step double-and-add); only
+// s*Ar + r*Bs1 has per-proof bases and is done here with a joint double-and-add.
 struct PkConsts {
-  G1Affine alpha, beta1, delta1;
-  G2Affine beta2, delta2;
+  G1Affine alpha, beta1;
+  G2Affine beta2;
 };
 struct ProofOut {
   G1Affine ar, krs;
   G2Affine bs;
 };
 
+// rs rows: [0] r, [1] s (inputs) -> [2] = -r*s
+__global__ __launch_bounds__(64) void rs_prep_kernel(Fr* rs, size_t Bp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bp) return;
+  rs[2 * Bp + i] = neg(mul(rs[i], rs[Bp + i]));
+}
+
 __global__ __launch_bounds__(64) void assemble_kernel(const G1XYZZ* sA, const G1XYZZ* sB1,
                                                       const G1XYZZ* sK, const G1XYZZ* sZ,
-                                                      const G2XYZZ* sB2, const Fr* rs, size_t Bp,
+                                                      const G1XYZZ* tR, const G1XYZZ* tS,
+                                                      const G1XYZZ* tNRS, const Fr* rs, size_t Bp,
                                                       PkConsts pk, ProofOut* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Bp) return;
-  const Fr rm = rs[i], sm = rs[Bp + i];
-  const Fr r = from_mont(rm), s = from_mont(sm);
-  const Fr nrs = from_mont(neg(mul(rm, sm)));
+  const Fr r = from_mont(rs[i]), s = from_mont(rs[Bp + i]);
   G1XYZZ AR = sA[i];
   madd(AR, pk.alpha);
-  {
-    G1XYZZ t = scalar_mul(pk.delta1, r.v);
-    padd(AR, t);
-  }
+  padd(AR, tR[i]);
   const G1Affine ar = to_affine(AR);
   G1XYZZ BS1 = sB1[i];
   madd(BS1, pk.beta1);
-  {
-    G1XYZZ t = scalar_mul(pk.delta1, s.v);
-    padd(BS1, t);
-  }
+  padd(BS1, tS[i]);
   const G1Affine bs1 = to_affine(BS1);
-  G1XYZZ KRS = sK[i];
-  {
-    G1XYZZ z = sZ[i];
-    padd(KRS, z);
-    G1XYZZ t = scalar_mul(pk.delta1, nrs.v);
-    padd(KRS, t);
-    t = scalar_mul(ar, s.v);
-    padd(KRS, t);
-    t = scalar_mul(bs1, r.v);
-    padd(KRS, t);
+  // s*ar + r*bs1, one shared doubling chain
+  G1XYZZ both = G1XYZZ::from_affine(ar);
+  madd(both, bs1);
+  G1XYZZ acc = G1XYZZ::inf();
+  for (int w = 7; w >= 0; w--) {
+    const uint32_t sw = s.v[w], rw = r.v[w];
+    for (int b = 31; b >= 0; b--) {
+      acc = dbl(acc);
+      const uint32_t sel = ((sw >> b) & 1u) | (((rw >> b) & 1u) << 1);
+      if (sel == 1)
+        madd(acc, ar);
+      else if (sel == 2)
+        madd(acc, bs1);
+      else if (sel == 3)
+        padd(acc, both);
+    }
   }
+  padd(acc, sK[i]);
+  padd(acc, sZ[i]);
+  padd(acc, tNRS[i]);
   out[i].ar = ar;
-  out[i].krs = to_affine(KRS);
+  out[i].krs = to_affine(acc);
 }
 
-__global__ __launch_bounds__(64) void assemble_g2_kernel(const G2XYZZ* sB2, const Fr* rs, size_t Bp,
-                                                         G2Affine beta2, G2Affine delta2,
-                                                         ProofOut* out) {
+__global__ __launch_bounds__(64) void assemble_g2_kernel(const G2XYZZ* sB2, const G2XYZZ* tS2,
+                                                         size_t Bp, G2Affine beta2, ProofOut* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Bp) return;
-  const Fr s = from_mont(rs[Bp + i]);
   G2XYZZ BS = sB2[i];
   madd(BS, beta2);
-  G2XYZZ t = scalar_mul(delta2, s.v);
-  padd(BS, t);
+  padd(BS, tS2[i]);
   out[i].bs = to_affine(BS);
 }
 
@@ -205,6 +214,15 @@ int zkmi_init(int device, zkmi_ctx** out) {
     delete ctx;
     return ZKMI_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ZKMI_ERR_HIP;
+  }
+  for (auto& st : ctx->sets) {
+    hipEventCreate(&st.ev0);
+    hipEventCreate(&st.ev1);
+  }
   for (auto& e : ctx->ev) hipEventCreate(&e);
   for (auto& p : ctx->msm_ev) {
     hipEventCreate(&p[0]);
@@ -219,6 +237,12 @@ void zkmi_destroy(zkmi_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->stream2);
+  for (auto& st : ctx->sets) {
+    if (st.ev0) hipEventDestroy(st.ev0);
+    if (st.ev1) hipEventDestroy(st.ev1);
+  }
+  hipStreamDestroy(ctx->stream2);
   for (auto& p : ctx->plans) {
     hipFree(p.tw_fwd);
     hipFree(p.tw_inv);
@@ -268,6 +292,10 @@ int zkmi_field_mul(zkmi_ctx* ctx, int which, const void* a, const void* b, void*
 
 int zkmi_field_mul_bench(zkmi_ctx* ctx, int which, size_t n_threads, int iters, double* rate) {
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   n_threads = round_up(n_threads, 256);
   void* buf;
   int rc = ensure_scratch(ctx, 5, n_threads * 32, &buf);
@@ -298,6 +326,10 @@ int zkmi_field_mul_bench(zkmi_ctx* ctx, int which, size_t n_threads, int iters, 
 
 int zkmi_ntt_batch(zkmi_ctx* ctx, void* data, int log_n, size_t batch, int inverse, int coset) {
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   if (batch == 0) return ZKMI_OK;
   NttPlan* plan;
   int rc = get_plan(ctx, log_n, &plan);
@@ -320,6 +352,10 @@ int zkmi_ntt_batch(zkmi_ctx* ctx, void* data, int log_n, size_t batch, int inver
 int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, void* h_out,
                  int log_n, size_t batch) {
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   if (batch == 0) return ZKMI_OK;
   NttPlan* plan;
   int rc = get_plan(ctx, log_n, &plan);
@@ -368,6 +404,10 @@ void zkmi_msm_bases_free(zkmi_ctx* ctx, zkmi_msm_bases* b) {
 int zkmi_msm_batch(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const void* scalars, size_t batch,
                    void* out) {
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   if (batch == 0) return ZKMI_OK;
   const size_t n = bases->n, Bp = round_up(batch, 64);
   const size_t pt = bases->group == 1 ? 64 : 128;
@@ -392,6 +432,10 @@ int zkmi_fixed_base_mul(zkmi_ctx* ctx, int group, const void* base, const void* 
                         void* out) {
   // an MSM over ONE base with the scalars playing the role of the batch
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   if (n == 0) return ZKMI_OK;
   zkmi_msm_bases* b = nullptr;
   int rc = zkmi_msm_bases_load(ctx, group, base, 1, 8, &b);
@@ -437,6 +481,9 @@ void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk) {
   zkmi_msm_bases_free(ctx, pk->K);
   zkmi_msm_bases_free(ctx, pk->Z);
   zkmi_msm_bases_free(ctx, pk->B2);
+  zkmi_msm_bases_free(ctx, pk->D1);
+  zkmi_msm_bases_free(ctx, pk->D2);
+  if (pk->idx3) hipFree(pk->idx3);
   if (pk->a_wire) hipFree(pk->a_wire);
   if (pk->b_wire) hipFree(pk->b_wire);
   if (pk->k_wire) hipFree(pk->k_wire);
@@ -473,6 +520,15 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       (rc = zkmi_msm_bases_load(ctx, 2, d->g2_b, d->n_b, c2, &pk->B2))) {
     zkmi_pk_free(ctx, pk);
     return rc;
+  }
+  {
+    const uint32_t idx[3] = {0, 1, 2};
+    if ((rc = upload_u32(ctx, idx, 3, &pk->idx3)) ||
+        (rc = zkmi_msm_bases_load(ctx, 1, d->g1_delta, 1, 8, &pk->D1)) ||
+        (rc = zkmi_msm_bases_load(ctx, 2, d->g2_delta, 1, 8, &pk->D2))) {
+      zkmi_pk_free(ctx, pk);
+      return rc;
+    }
   }
   hipMemcpy(&pk->alpha, d->g1_alpha, 64, hipMemcpyDefault);
   hipMemcpy(&pk->beta1, d->g1_beta, 64, hipMemcpyDefault);
@@ -581,6 +637,10 @@ static int stage_inputs(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs_dev
 int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_t batch,
                      void* wires_out, void* abc_out, int32_t* status_out) {
   ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted prove batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
   if (batch == 0) return ZKMI_OK;
   const size_t Bp = round_up(batch, 64);
   const size_t n_in = cs->n_public - 1 + cs->n_secret;
@@ -615,10 +675,17 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
   return ZKMI_OK;
 }
 
-int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
-                     size_t batch, const void* rs, void* proofs_out, int32_t* status_out) {
+static bool any_pending(zkmi_ctx* ctx) { return ctx->sets[0].pending || ctx->sets[1].pending; }
+
+// Stage 1 of a prove: inputs -> value file, witness solve.  Runs on stream2 so that it overlaps
+// the NTT/MSM kernels of the previously submitted batch (the solve is a 16-wavefront latency chain).
+int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
+                      size_t batch, const void* rs) {
   ZK_HIP(hipSetDevice(ctx->device));
-  if (batch == 0) return ZKMI_OK;
+  if (batch == 0) {
+    ctx->err = "prove: empty batch";
+    return ZKMI_ERR_ARG;
+  }
   if (pk->n_wires != cs->n_wires) {
     ctx->err = "prove: proving key and constraint system disagree on the number of wires";
     return ZKMI_ERR_ARG;
@@ -627,82 +694,171 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
     ctx->err = "prove: domain smaller than the number of constraints";
     return ZKMI_ERR_ARG;
   }
-  NttPlan* plan;
-  int rc = get_plan(ctx, (int)pk->log_n, &plan);
-  if (rc) return rc;
+  const int si = ctx->next_submit;
+  zkmi_ctx::ProveSet& S = ctx->sets[si];
+  if (S.pending) {
+    ctx->err = "prove: two batches already in flight; collect one first";
+    return ZKMI_ERR_ARG;
+  }
   const size_t Bp = round_up(batch, 64);
   const size_t n = (size_t)1 << pk->log_n;
   const size_t n_in = cs->n_public - 1 + cs->n_secret;
-  Staged si(ctx), srs(ctx), sp(ctx), sst(ctx);
-  if ((rc = si.in(inputs, batch * n_in * 32)) || (rc = srs.in(rs, batch * 64)) ||
-      (rc = sp.out(proofs_out, batch * 256)) || (rc = sst.out(status_out, batch * 4)))
+  int rc;
+  const int base = si == 0 ? 0 : 8;   // scratch slots 0-3,5 (set 0) / 8-11,13 (set 1)
+  void* misc;
+  {  // size the other set too, so steady-state submits never allocate
+    void* dummy;
+    const int ob = si == 0 ? 8 : 0;
+    if ((rc = ensure_scratch(ctx, ob + 0, (size_t)cs->n_slots * Bp * 32, &dummy)) ||
+        (rc = ensure_scratch(ctx, ob + 1, n * Bp * 32, &dummy)) ||
+        (rc = ensure_scratch(ctx, ob + 2, n * Bp * 32, &dummy)) ||
+        (rc = ensure_scratch(ctx, ob + 3, n * Bp * 32, &dummy)) ||
+        (rc = ensure_scratch(ctx, ob + 5, Bp * (96 + 4) + batch * (n_in * 32 + 64), &dummy)))
+      return rc;
+  }
+  if ((rc = ensure_scratch(ctx, base + 0, (size_t)cs->n_slots * Bp * 32, &S.slots)) ||
+      (rc = ensure_scratch(ctx, base + 1, n * Bp * 32, &S.a)) ||
+      (rc = ensure_scratch(ctx, base + 2, n * Bp * 32, &S.b)) ||
+      (rc = ensure_scratch(ctx, base + 3, n * Bp * 32, &S.c)) ||
+      (rc = ensure_scratch(ctx, base + 5, Bp * (96 + 4) + batch * (n_in * 32 + 64), &misc)))
     return rc;
-  void *slots, *a, *b, *c, *t0, *misc;
-  const size_t misc_bytes = Bp * (4 /*status*/ + 64 /*rs*/ + 4 * 128 + 256 /*sums*/ + 256);
-  if ((rc = ensure_scratch(ctx, 0, (size_t)cs->n_slots * Bp * 32, &slots)) ||
-      (rc = ensure_scratch(ctx, 1, n * Bp * 32, &a)) ||
-      (rc = ensure_scratch(ctx, 2, n * Bp * 32, &b)) ||
-      (rc = ensure_scratch(ctx, 3, n * Bp * 32, &c)) ||
-      (rc = ensure_scratch(ctx, 4, n * Bp * 32, &t0)) ||
-      (rc = ensure_scratch(ctx, 5, misc_bytes, &misc)))
+  S.rs = misc;
+  S.st = (char*)misc + Bp * 96;
+  char* stage_in = (char*)misc + Bp * 100;
+  char* stage_rs = stage_in + batch * n_in * 32;
+  hipStream_t q = ctx->stream2;
+  // caller buffers are consumed before this function returns only if they are host memory
+  // (pageable copies are synchronous); device buffers must stay valid until the collect
+  const void* in_dev = inputs;
+  const void* rs_dev = rs;
+  if (!is_device_ptr(inputs)) {
+    ZK_HIP(hipMemcpyAsync(stage_in, inputs, batch * n_in * 32, hipMemcpyHostToDevice, q));
+    in_dev = stage_in;
+  }
+  if (!is_device_ptr(rs)) {
+    ZK_HIP(hipMemcpyAsync(stage_rs, rs, batch * 64, hipMemcpyHostToDevice, q));
+    rs_dev = stage_rs;
+  }
+  hipStream_t saved = ctx->stream;
+  ctx->stream = q;  // the helpers launch on ctx->stream
+  hipEventRecord(S.ev0, q);
+  rc = transpose_in(ctx, in_dev, (Fr*)S.slots + Bp, n_in, batch, Bp, 32);
+  if (!rc) rc = transpose_in(ctx, rs_dev, S.rs, 2, batch, Bp, 32);
+  if (!rc)
+    rc = solve_bi(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp);
+  hipEventRecord(S.ev1, q);
+  ctx->stream = saved;
+  if (rc) return rc;
+  S.pending = true;
+  S.batch = batch;
+  S.Bp = Bp;
+  S.pk = pk;
+  S.cs = cs;
+  ctx->next_submit ^= 1;
+  return ZKMI_OK;
+}
+
+// Stage 2: quotient, MSMs, assembly of the oldest submitted batch; blocks until its proofs are
+// in proofs_out / status_out.
+int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  zkmi_ctx::ProveSet& S = ctx->sets[ctx->next_collect];
+  if (!S.pending) {
+    ctx->err = "prove: nothing submitted";
+    return ZKMI_ERR_ARG;
+  }
+  const zkmi_pk* pk = S.pk;
+  const zkmi_cs* cs = S.cs;
+  const size_t batch = S.batch, Bp = S.Bp;
+  const size_t n = (size_t)1 << pk->log_n;
+  NttPlan* plan;
+  int rc = get_plan(ctx, (int)pk->log_n, &plan);
+  if (rc) return rc;
+  Staged sp(ctx), sst(ctx);
+  if ((rc = sp.out(proofs_out, batch * 256)) || (rc = sst.out(status_out, batch * 4))) return rc;
+  void *t0, *misc;
+  const size_t misc_bytes = Bp * (7 * 128 + 2 * 256 + 256);
+  if ((rc = ensure_scratch(ctx, 4, n * Bp * 32, &t0)) ||
+      (rc = ensure_scratch(ctx, 14, misc_bytes, &misc)))
     return rc;
   char* m = (char*)misc;
-  Fr* rs_bi = (Fr*)m;                       m += Bp * 64;
+  Fr* rs_bi = (Fr*)S.rs;
   G1XYZZ* sA = (G1XYZZ*)m;                  m += Bp * 128;
   G1XYZZ* sB1 = (G1XYZZ*)m;                 m += Bp * 128;
   G1XYZZ* sK = (G1XYZZ*)m;                  m += Bp * 128;
   G1XYZZ* sZ = (G1XYZZ*)m;                  m += Bp * 128;
+  G1XYZZ* tR = (G1XYZZ*)m;                  m += Bp * 128;
+  G1XYZZ* tS = (G1XYZZ*)m;                  m += Bp * 128;
+  G1XYZZ* tNRS = (G1XYZZ*)m;                m += Bp * 128;
   G2XYZZ* sB2 = (G2XYZZ*)m;                 m += Bp * 256;
-  ProofOut* proofs = (ProofOut*)m;          m += Bp * 256;
-  int32_t* st = (int32_t*)m;
+  G2XYZZ* tS2 = (G2XYZZ*)m;                 m += Bp * 256;
+  ProofOut* proofs = (ProofOut*)m;
+  Fr* slots = (Fr*)S.slots;
 
-  hipEventRecord(ctx->ev[0], ctx->stream);
-  if ((rc = stage_inputs(ctx, cs, si.dev, batch, Bp, (Fr*)slots))) return rc;
-  if ((rc = transpose_in(ctx, srs.dev, rs_bi, 2, batch, Bp, 32))) return rc;
-  if ((rc = solve_bi(ctx, cs, (Fr*)slots, (Fr*)a, (Fr*)b, (Fr*)c, st, Bp))) return rc;
+  ZK_HIP(hipStreamWaitEvent(ctx->stream, S.ev1, 0));
   hipEventRecord(ctx->ev[1], ctx->stream);
   Fr* h;
-  if ((rc = compute_h_bi(ctx, plan, (Fr*)a, (Fr*)b, (Fr*)c, (Fr*)t0, Bp, cs->n_constraints, &h)))
+  if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, cs->n_constraints,
+                         &h)))
     return rc;
   hipEventRecord(ctx->ev[2], ctx->stream);
   ctx->msm_ev_used = 0;
   ctx->msm_ev_on = true;
-  if ((rc = msm_run(ctx, pk->A, (const Fr*)slots, pk->a_wire, Bp, sA)) ||
-      (rc = msm_run(ctx, pk->B1, (const Fr*)slots, pk->b_wire, Bp, sB1)) ||
-      (rc = msm_run(ctx, pk->K, (const Fr*)slots, pk->k_wire, Bp, sK)) ||
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, sA)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, sB1)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, sK)) ||
       (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, sZ)))
     return rc;
   hipEventRecord(ctx->ev[3], ctx->stream);
-  if ((rc = msm_run(ctx, pk->B2, (const Fr*)slots, pk->b_wire, Bp, sB2))) return rc;
+  if ((rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, sB2))) return rc;
   hipEventRecord(ctx->ev[4], ctx->stream);
   ctx->msm_ev_on = false;
-  PkConsts pc{pk->alpha, pk->beta1, pk->delta1, pk->beta2, pk->delta2};
+  hipLaunchKernelGGL(rs_prep_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, rs_bi, Bp);
+  if ((rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 0, Bp, tR)) ||
+      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 1, Bp, tS)) ||
+      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, tNRS)) ||
+      (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, tS2)))
+    return rc;
+  PkConsts pc{pk->alpha, pk->beta1, pk->beta2};
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, sA, sB1,
-                     sK, sZ, sB2, rs_bi, Bp, pc, proofs);
+                     sK, sZ, tR, tS, tNRS, rs_bi, Bp, pc, proofs);
   hipLaunchKernelGGL(assemble_g2_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, sB2,
-                     rs_bi, Bp, pk->beta2, pk->delta2, proofs);
+                     tS2, Bp, pk->beta2, proofs);
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipMemcpyAsync(sp.dev, proofs, batch * 256, hipMemcpyDeviceToDevice, ctx->stream));
-  ZK_HIP(hipMemcpyAsync(sst.dev, st, batch * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  ZK_HIP(hipMemcpyAsync(sst.dev, S.st, batch * 4, hipMemcpyDeviceToDevice, ctx->stream));
   hipEventRecord(ctx->ev[5], ctx->stream);
   if ((rc = sp.finish()) || (rc = sst.finish())) return rc;
   ZK_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 5; i++) {
-    float ms = 0;
+  S.pending = false;
+  ctx->next_collect ^= 1;
+  float ms = 0;
+  hipEventElapsedTime(&ms, S.ev0, S.ev1);
+  ctx->timings[0] = ms;
+  for (int i = 1; i < 5; i++) {
     hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
     ctx->timings[i] = ms;
   }
-  float tot = 0;
-  hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[5]);
-  ctx->timings[5] = tot;
+  hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]);
+  ctx->timings[5] = ms;  // device time of stage 2 (solve overlaps the previous batch)
   ctx->timings[6] = ctx->timings[7] = 0;
   for (int i = 0; i < ctx->msm_ev_used; i++) {
-    float ms = 0;
     hipEventElapsedTime(&ms, ctx->msm_ev[i][0], ctx->msm_ev[i][1]);
     ctx->timings[ctx->msm_ev_group[i] == 1 ? 6 : 7] += ms;
   }
-  // per-proof status is reported in status_out; the call itself succeeded
   return ZKMI_OK;
+}
+
+int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
+                     size_t batch, const void* rs, void* proofs_out, int32_t* status_out) {
+  if (batch == 0) return ZKMI_OK;
+  if (any_pending(ctx)) {
+    ctx->err = "prove_batch: batches submitted with zkmi_prove_submit are still in flight";
+    return ZKMI_ERR_ARG;
+  }
+  int rc = zkmi_prove_submit(ctx, pk, cs, inputs, batch, rs);
+  if (rc) return rc;
+  return zkmi_prove_collect(ctx, proofs_out, status_out);
 }
 
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out) {

@@ -41,7 +41,19 @@ struct zkmi_ctx {
   hipEvent_t ev[8] = {};
   double timings[8] = {};
   // scratch arena for the prove pipeline, grown on demand
-  zk::DevBuf scratch[8];
+  zk::DevBuf scratch[16];
+  // software pipeline over batches: the latency-bound witness solve of batch k+1 runs on
+  // `stream2` (16 wavefronts at batch 1024) underneath the NTT/MSM kernels of batch k.
+  hipStream_t stream2 = nullptr;
+  struct ProveSet {
+    bool pending = false;
+    size_t batch = 0, Bp = 0;
+    const zkmi_pk* pk = nullptr;
+    const zkmi_cs* cs = nullptr;
+    void *slots = nullptr, *a = nullptr, *b = nullptr, *c = nullptr, *rs = nullptr, *st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // solve start / end on stream2
+  } sets[2];
+  int next_submit = 0, next_collect = 0;
   // HIP event pairs bracketing every msm_accumulate launch of the current prove call
   hipEvent_t msm_ev[16][2] = {};
   int msm_ev_group[16] = {};
@@ -62,6 +74,8 @@ struct zkmi_pk {
   uint32_t log_n = 0, n_wires = 0, n_a = 0, n_b = 0, n_k = 0, n_z = 0;
   uint32_t *a_wire = nullptr, *b_wire = nullptr, *k_wire = nullptr;  // device
   zkmi_msm_bases *A = nullptr, *B1 = nullptr, *K = nullptr, *Z = nullptr, *B2 = nullptr;
+  zkmi_msm_bases *D1 = nullptr, *D2 = nullptr;  // one-base tables of delta (G1, G2)
+  uint32_t* idx3 = nullptr;                      // device {0, 1, 2}
   zk::G1Affine alpha, beta1, delta1;
   zk::G2Affine beta2, delta2;
 };

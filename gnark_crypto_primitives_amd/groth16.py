@@ -197,3 +197,31 @@ class Prover:
             status_out = np.zeros(batch, dtype=np.int32)
         self.ctx.prove_batch(self.pk_h, self.cs_h, inputs, batch, rs, proofs_out, status_out)
         return proofs_out, status_out
+
+    def submit(self, inputs, rs):
+        """Stage 1 (inputs + witness solve) of a batch; overlaps the previous batch's stage 2."""
+        self.ctx.prove_submit(self.pk_h, self.cs_h, inputs, inputs.shape[0], rs)
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((inputs, rs, inputs.shape[0]))     # keep buffers alive
+
+    def collect(self, proofs_out=None, status_out=None):
+        """Stage 2 (quotient, MSMs, assembly) of the oldest submitted batch."""
+        _, _, batch = self._inflight.pop(0)
+        if proofs_out is None:
+            proofs_out = np.zeros((batch, 32), dtype=np.uint64)
+        if status_out is None:
+            status_out = np.zeros(batch, dtype=np.int32)
+        self.ctx.prove_collect(proofs_out, status_out)
+        return proofs_out, status_out
+
+    def prove_stream(self, batches):
+        """Generator over (inputs, rs) batches, software-pipelined two deep."""
+        it = iter(batches)
+        try:
+            self.submit(*next(it))
+        except StopIteration:
+            return
+        for nxt in it:
+            self.submit(*nxt)
+            yield self.collect()
+        yield self.collect()

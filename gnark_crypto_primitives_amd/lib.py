@@ -57,6 +57,8 @@ SYMBOLS = [
     ("zkmi_cs_free", None, [_P, _P]),
     ("zkmi_solve_batch", _I, [_P, _P, _P, _SZ, _P, _P, _P]),
     ("zkmi_prove_batch", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P]),
+    ("zkmi_prove_submit", _I, [_P, _P, _P, _P, _SZ, _P]),
+    ("zkmi_prove_collect", _I, [_P, _P, _P]),
     ("zkmi_last_timings", _I, [_P, C.POINTER(C.c_double)]),
 ]
 
@@ -201,6 +203,14 @@ class Context:
         self._check(self.lib.zkmi_prove_batch(self.h, pk_h, cs_h, _ptr(inputs), batch, _ptr(rs),
                                               _ptr(proofs_out), _ptr(status_out)),
                     "zkmi_prove_batch")
+
+    def prove_submit(self, pk_h, cs_h, inputs, batch, rs):
+        self._check(self.lib.zkmi_prove_submit(self.h, pk_h, cs_h, _ptr(inputs), batch, _ptr(rs)),
+                    "zkmi_prove_submit")
+
+    def prove_collect(self, proofs_out, status_out):
+        self._check(self.lib.zkmi_prove_collect(self.h, _ptr(proofs_out), _ptr(status_out)),
+                    "zkmi_prove_collect")
 
     def last_timings(self):
         arr = (C.c_double * 8)()

@@ -141,9 +141,19 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
 int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                      size_t batch, const void* rs, void* proofs_out, int32_t* status_out);
 
+/* The same prove split in two so that consecutive batches overlap: `submit` stages the inputs and
+ * runs the witness solve on a second HIP stream, `collect` runs quotient + MSMs + assembly of the
+ * OLDEST submitted batch and blocks until its proofs are written.  At most two batches may be in
+ * flight; submit(k+1) before collect(k) hides the latency-bound solve under batch k's MSMs.
+ * Device-pointer inputs / rs must stay valid until the matching collect.  While a batch is in
+ * flight the other entry points of the same context return ZKMI_ERR_ARG. */
+int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
+                      size_t batch, const void* rs);
+int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
+
 /* Per-stage device time of the last zkmi_prove_batch, milliseconds, measured with HIP events on
  * the context's stream: [0] solve, [1] quotient (NTTs + pointwise), [2] G1 MSMs, [3] G2 MSM,
- * [4] assembly, [5] total, [6] sum over the four G1 msm_accumulate kernel launches alone (event
+ * [4] assembly, [5] quotient..assembly total (the solve overlaps the previous batch), [6] sum over the four G1 msm_accumulate kernel launches alone (event
  * pair around each launch), [7] the G2 msm_accumulate launch alone. */
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out /* 8 doubles */);
 

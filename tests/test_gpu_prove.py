@@ -124,3 +124,31 @@ def test_smt_inclusion_prove(zk_ctx, levels, populated):
     ok = status == 0
     assert np.array_equal(proofs[ok], want[ok])
     prover.close()
+
+
+def test_pipelined_submit_collect_matches_blocking(zk_ctx, poseidon_setup):
+    """submit(k+1) before collect(k): same proofs as the blocking call, batches of different sizes,
+    one unsatisfied witness, and the guard against mixing entry points while a batch is in flight."""
+    from gnark_crypto_primitives_amd import lib
+    from oracle import pyref
+    cc, pk, vk, td, prover = poseidon_setup
+    rng = random.Random(8)
+    batches = []
+    for bsz in (5, 70, 1, 64):
+        datas = [rng.randrange(pyref.R) for _ in range(bsz)]
+        inp = np.stack([to_mont_array(cc.assignment_vector(
+            {"Data": d, "Hash": pyref.poseidon_hash([d])})) for d in datas])
+        rs = np.stack([to_mont_array([rng.randrange(pyref.R), rng.randrange(pyref.R)])
+                       for _ in range(bsz)])
+        batches.append((inp, rs))
+    batches[1][0][3, 0, 0] ^= 1
+    want = [prover.prove(i, r) for i, r in batches]
+    got = list(prover.prove_stream(batches))
+    for (wp, ws), (gp, gs) in zip(want, got):
+        assert np.array_equal(ws, gs)
+        assert np.array_equal(wp[ws == 0], gp[gs == 0])
+    assert list(got[1][1] != 0) == [i == 3 for i in range(70)]
+    prover.submit(*batches[0])
+    with pytest.raises(lib.ZkmiError):
+        prover.solve(batches[0][0])
+    prover.collect()
