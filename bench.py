@@ -44,8 +44,8 @@ def available_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--levels", type=int, default=160)
     ap.add_argument("--populated", type=int, default=10, help="non-zero siblings per path")
@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--window-g2", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="proofs for the CPU baseline (-1: 2 per core, 0: skip)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one blocking zkmi_prove_batch per step (no overlap of consecutive steps)")
     ap.add_argument("--verbose", action="store_true")
@@ -66,10 +70,16 @@ def main():
     from gnark_crypto_primitives_amd.tree import smt_witness
 
     rank, world, local_rank = backend.env_rank_world()
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.device >= 0:
+        local_rank = args.device
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # collectives' tensors
+    if world > 1:
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) \
         else (lambda *a: None)
 
@@ -125,13 +135,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     status = status_d.cpu().numpy()
     n_bad = int((status != 0).sum())
     if world > 1:
-        t = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_bad], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         n_bad = int(t.item())
     proofs = proofs_d.cpu().numpy().view(np.uint64)

@@ -143,7 +143,7 @@ struct ProofOut {
 __global__ __launch_bounds__(64) void rs_prep_kernel(Fr* rs, size_t Bp) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Bp) return;
-  rs[2 * Bp + i] = neg(mul(rs[i], rs[Bp + i]));
+  bi_st(rs, 2, i, Bp, neg(mul(bi_ld(rs, 0, i, Bp), bi_ld(rs, 1, i, Bp))));
 }
 
 __global__ __launch_bounds__(64) void assemble_kernel(const G1XYZZ* sA, const G1XYZZ* sB1,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void assemble_kernel(const G1XYZZ* sA, const G1
                                                       PkConsts pk, ProofOut* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Bp) return;
-  const Fr r = from_mont(rs[i]), s = from_mont(rs[Bp + i]);
+  const Fr r = from_mont(bi_ld(rs, 0, i, Bp)), s = from_mont(bi_ld(rs, 1, i, Bp));
   G1XYZZ AR = sA[i];
   madd(AR, pk.alpha);
   padd(AR, tR[i]);
@@ -451,9 +451,8 @@ int zkmi_fixed_base_mul(zkmi_ctx* ctx, int group, const void* base, const void* 
     zkmi_msm_bases_free(ctx, b);
     return rc;
   }
-  hipMemsetAsync(sbi, 0, Bp * 32, ctx->stream);
-  hipMemcpyAsync(sbi, ss.dev, n * 32, hipMemcpyDeviceToDevice, ctx->stream);
-  rc = msm_run(ctx, b, (const Fr*)sbi, nullptr, Bp, acc);
+  rc = transpose_in(ctx, ss.dev, sbi, 1, n, Bp, 32);   // one row of n scalars, batch-inner
+  if (!rc) rc = msm_run(ctx, b, (const Fr*)sbi, nullptr, Bp, acc);
   if (!rc) rc = xyzz_to_affine(ctx, group, acc, aff, Bp);
   if (!rc) {
     hipMemcpyAsync(so.dev, aff, n * pt, hipMemcpyDeviceToDevice, ctx->stream);

@@ -61,8 +61,10 @@ ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
   }
   const Fq29 ppp = mul(p, pp);
   const Fq29 q = mul(acc.x, pp);
-  const Fq29 x3 = norm(sub(sub(rr, ppp), add(q, q)));             // (-5p, 3p)
-  const Fq29 y3 = norm(sub(mul(r, sub(q, x3)), mul(acc.y, ppp)));  // (-2p, 2p)
+  const Fq29 x3 = norm(sub(sub(rr, ppp), add(q, q)));  // (-5p, 3p)
+  // y3 = r*(q - x3) - y1*ppp with ONE Montgomery reduction for both products (saves 90 of the
+  // 342 mads and the normalisation); |r (q-x3)| + |y1 ppp| < 26 p^2, result in (-p/2, 3p/2)
+  const Fq29 y3 = mul_add2(r, sub(q, x3), neg(acc.y), ppp);
   acc.zz = mul(acc.zz, pp);
   acc.zzz = mul(acc.zzz, ppp);
   acc.x = x3;

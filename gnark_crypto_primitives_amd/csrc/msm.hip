@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
   typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t i = i0; i < i1; i++) {
     const uint32_t row = row_idx ? row_idx[i] : i;
-    Fr s = from_mont(scalars[(size_t)row * Bp + b]);
+    Fr s = from_mont(bi_ld(scalars, row, b, Bp));
     if (s.is_zero()) continue;
     const Affine<F>* trow = table + (((size_t)i * W) << (c - 1));
     uint32_t carry = 0;

@@ -26,51 +26,52 @@ __global__ __launch_bounds__(64) void solve_kernel(const uint4* __restrict__ pro
   const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t k = 0;
   int32_t st = 0;
-#define SLOT(i) slots[(size_t)(i) * Bp + lane]
+#define LD(i) bi_ld(slots, (i), lane, Bp)
+#define ST(i, v) bi_st(slots, (i), lane, Bp, (v))
   for (uint32_t pc = 0; pc < n_ops; pc++) {
     const uint4 ins = prog[pc];
     const uint32_t op = ins.x & 0xffu;
     const uint32_t d = ins.y, x = ins.z, y = ins.w;
     switch (op) {
       case OP_ADD:
-        SLOT(d) = add(SLOT(x), SLOT(y));
+        ST(d, add(LD(x), LD(y)));
         break;
       case OP_SUB:
-        SLOT(d) = sub(SLOT(x), SLOT(y));
+        ST(d, sub(LD(x), LD(y)));
         break;
       case OP_MUL:
-        SLOT(d) = mul(SLOT(x), SLOT(y));
+        ST(d, mul(LD(x), LD(y)));
         break;
       case OP_MULC:
-        SLOT(d) = mul(SLOT(x), consts[y]);
+        ST(d, mul(LD(x), consts[y]));
         break;
       case OP_ADDC:
-        SLOT(d) = add(SLOT(x), consts[y]);
+        ST(d, add(LD(x), consts[y]));
         break;
       case OP_NEG:
-        SLOT(d) = neg(SLOT(x));
+        ST(d, neg(LD(x)));
         break;
       case OP_INV:
-        SLOT(d) = inverse(SLOT(x));
+        ST(d, inverse(LD(x)));
         break;
       case OP_DIV:
-        SLOT(d) = mul(SLOT(x), inverse(SLOT(y)));
+        ST(d, mul(LD(x), inverse(LD(y))));
         break;
       case OP_SETC:
-        SLOT(d) = consts[y];
+        ST(d, consts[y]);
         break;
       case OP_COPY:
-        SLOT(d) = SLOT(x);
+        ST(d, LD(x));
         break;
       case OP_BITS: {
-        Fr v = from_mont(SLOT(x));
+        Fr v = from_mont(LD(x));
         const Fr one = Fr::one(), zero = Fr::zero();
         for (uint32_t i = 0; i < y; i++) {
           const uint32_t bit = i < 256 ? (v.v[0] & 1u) : 0u;
 #pragma unroll
           for (int l = 0; l < 7; l++) v.v[l] = (v.v[l] >> 1) | (v.v[l + 1] << 31);
           v.v[7] >>= 1;
-          SLOT(d + i) = bit ? one : zero;
+          ST(d + i, bit ? one : zero);
         }
         break;
       }
@@ -81,30 +82,30 @@ __global__ __launch_bounds__(64) void solve_kernel(const uint4* __restrict__ pro
         Fr acc = Fr::one();
         for (uint32_t k = 1; k <= n; k++) {
           const uint4 pr = prog[pc + k];
-          const Fr v = SLOT(pr.z);
-          SLOT(pr.y) = acc;
+          const Fr v = LD(pr.z);
+          ST(pr.y, acc);
           if (!v.is_zero()) acc = mul(acc, v);
         }
         Fr inv = inverse(acc);
         for (uint32_t k = n; k >= 1; k--) {
           const uint4 pr = prog[pc + k];
-          const Fr v = SLOT(pr.z);
+          const Fr v = LD(pr.z);
           if (v.is_zero()) {
-            SLOT(pr.y) = Fr::zero();
+            ST(pr.y, Fr::zero());
           } else {
-            const Fr res = mul(inv, SLOT(pr.y));
+            const Fr res = mul(inv, LD(pr.y));
             inv = mul(inv, v);
-            SLOT(pr.y) = res;
+            ST(pr.y, res);
           }
         }
         pc += n;
         break;
       }
       case OP_ABC: {
-        const Fr va = SLOT(d), vb = SLOT(x), vc = SLOT(y);
-        a[(size_t)k * Bp + lane] = va;
-        b[(size_t)k * Bp + lane] = vb;
-        c[(size_t)k * Bp + lane] = vc;
+        const Fr va = LD(d), vb = LD(x), vc = LD(y);
+        bi_st(a, k, lane, Bp, va);
+        bi_st(b, k, lane, Bp, vb);
+        bi_st(c, k, lane, Bp, vc);
         if (ins.x & 0x100u) {
           if (mul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
         }
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(64) void solve_kernel(const uint4* __restrict__ pro
         break;
     }
   }
-#undef SLOT
+#undef LD
+#undef ST
   status[lane] = st;
 }
 
 __global__ void fill_one_row(Fr* row, size_t Bp) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < Bp) row[i] = Fr::one();
+  if (i < Bp) bi_st(row, 0, i, Bp, Fr::one());
 }
 
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,

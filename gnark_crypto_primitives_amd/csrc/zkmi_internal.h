@@ -15,6 +15,11 @@ namespace zk {
 // wavefront work on 64 different proofs at the same row: loads/stores are 2 KiB contiguous per
 // wave, and everything indexed by row (twiddles, constants, window-table slices, program words)
 // is wave-uniform and comes through the scalar unit.  Bp = batch rounded up to 64.
+// Within a row the two 16-byte halves of the elements are stored as two planes
+// ([row][half][proof]): a lane's 32-byte element is then two dwordx4 accesses that are each
+// perfectly coalesced across the wave (1 KiB contiguous).  With the halves interleaved
+// ([row][proof][half]) every vector store wrote 16 of each 32 bytes and rocprofv3 showed 3x read /
+// 6x write amplification on the NTT passes (profiles/r01_pmc_*.csv).
 
 struct DevBuf {
   void* p = nullptr;
@@ -88,6 +93,23 @@ struct zkmi_cs {
 };
 
 namespace zk {
+
+#if defined(__HIPCC__)
+// element (row, b) of a batch-inner matrix with row pitch Bp
+__device__ __forceinline__ Fr bi_ld(const Fr* base, size_t row, size_t b, size_t Bp) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + row * 2 * Bp + b;
+  const uint4 lo = p[0], hi = p[Bp];
+  Fr r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+__device__ __forceinline__ void bi_st(Fr* base, size_t row, size_t b, size_t Bp, const Fr& x) {
+  uint4* p = reinterpret_cast<uint4*>(base) + row * 2 * Bp + b;
+  p[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  p[Bp] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+#endif
 
 // witness-program opcodes (frontend/api.py)
 enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC,

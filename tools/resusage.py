@@ -5,7 +5,8 @@ import subprocess
 import sys
 
 out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
-                      "--offload-device-only", "-Rpass-analysis=kernel-resource-usage", "-c",
+                      "--offload-device-only", "-mllvm", "-pragma-unroll-threshold=1000000",
+                      "-Rpass-analysis=kernel-resource-usage", "-c",
                       sys.argv[1], "-o", "/dev/null"], capture_output=True, text=True).stderr
 rows, cur = [], None
 keys = {"VGPRs": "vgpr", "VGPR Spill": "spill", "ScratchSize [bytes/lane]": "scratch",
