@@ -1,8 +1,10 @@
 """The circuits BASELINE.json's configs name, as the reference's own tests define them."""
+from .elgamal import Ciphertext, DecryptionProof
 from .frontend import Public, Secret
 from .hash import poseidon
+from .std.twistededwards import Point
 from .tree import smt
-from .utils import PoseidonHasher
+from .utils import PoseidonHasher, PoseidonMultiHasher
 
 
 class PoseidonCircuit:
@@ -48,3 +50,44 @@ def smt_verifier_circuit(levels: int):
                                  self.OldValue, self.IsOld0, self.Key, self.Value, self.Fnc)
             api.AssertIsEqual(valid, 1)
     return SmtVerifier()
+
+
+class ElGamalAddCircuit:
+    """testElGamalAddCircuit (elgamal/ciphertext_test.go:25-37): config 4.  A, B, Sum public."""
+    A = Public(4)
+    B = Public(4)
+    Sum = Public(4)
+
+    def define(self, api):
+        ct = lambda v: Ciphertext(Point(v[0], v[1]), Point(v[2], v[3]))
+        ct(self.A).Add(api, ct(self.A), ct(self.B)).AssertIsEqual(api, ct(self.Sum))
+
+
+class ElGamalEncryptCircuit:
+    """Encrypt circuit of elgamal/encrypt_test.go:61-86 (config 4b): public key and expected
+    ciphertext public, k and m secret."""
+    PubKey = Public(2)
+    Expected = Public(4)
+    K = Secret()
+    M = Secret()
+
+    def define(self, api):
+        z = Ciphertext().Encrypt(api, Point(*self.PubKey), self.K, self.M)
+        e = self.Expected
+        z.AssertIsEqual(api, Ciphertext(Point(e[0], e[1]), Point(e[2], e[3])))
+
+
+class DecryptionProofCircuit:
+    """testVerifyDecryptionProofCircuit (elgamal/ciphertext_test.go:274-285)."""
+    PubKey = Public(2)
+    Ct = Public(4)
+    A1 = Public(2)
+    A2 = Public(2)
+    Z = Public()
+    Msg = Secret()
+
+    def define(self, api):
+        c = self.Ct
+        proof = DecryptionProof(Point(*self.A1), Point(*self.A2), self.Z)
+        proof.Verify(api, PoseidonMultiHasher, Point(*self.PubKey),
+                     Ciphertext(Point(c[0], c[1]), Point(c[2], c[3])), self.Msg)

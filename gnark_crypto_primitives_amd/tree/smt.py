@@ -146,3 +146,72 @@ def InclusionVerifier(api, hFn, root, siblings, key, value):
 
 def ExclusionVerifier(api, hFn, root, siblings, old_key, old_value, is_old0, key):
     return Verifier(api, hFn, 1, root, siblings, old_key, old_value, is_old0, key, 0, 1)
+
+
+# ---- processor (circomlib smtprocessor): tree/smt/processor.go:10-72, processor_level.go:10-27,
+# processor_sm.go:7-17 -----------------------------------------------------------------------------
+def ProcessorSM(api, xor, is0, lev_ins, fnc0, prev_top, prev_old0, prev_bot, prev_new1, prev_na,
+                prev_upd):
+    aux1 = api.Mul(prev_top, lev_ins)
+    aux2 = api.Mul(aux1, fnc0)
+    st_top = api.Sub(prev_top, aux1)
+    st_old0 = api.Mul(aux2, is0)
+    st_new1 = api.Mul(api.Add(api.Sub(aux2, st_old0), prev_bot), xor)
+    st_bot = api.Mul(api.Sub(1, xor), api.Add(api.Sub(aux2, st_old0), prev_bot))
+    st_upd = api.Sub(aux1, aux2)
+    st_na = api.Add(api.Add(api.Add(prev_new1, prev_old0), prev_na), prev_upd)
+    return st_top, st_old0, st_bot, st_new1, st_na, st_upd
+
+
+def ProcessorLevel(api, hFn, st_top, st_old0, st_bot, st_new1, st_upd, sibling, old1leaf, new1leaf,
+                   newlrbit, old_child, new_child):
+    old_l, old_r = Switcher(api, newlrbit, old_child, sibling)
+    old_proof_hash = Hash2(api, hFn, old_l, old_r)
+    old_root = api.Add(api.Mul(old1leaf, api.Add(st_bot, st_new1, st_upd)),
+                       api.Mul(old_proof_hash, st_top))
+    new_l, new_r = Switcher(
+        api, newlrbit,
+        api.Add(api.Mul(new_child, api.Add(st_top, st_bot)), api.Mul(new1leaf, st_new1)),
+        api.Add(api.Mul(sibling, st_top), api.Mul(old1leaf, st_new1)))
+    new_proof_hash = Hash2(api, hFn, new_l, new_r)
+    new_root = api.Add(api.Mul(new_proof_hash, api.Add(st_top, st_bot, st_new1)),
+                       api.Mul(new1leaf, api.Add(st_old0, st_upd)))
+    return old_root, new_root
+
+
+def ProcessorWithLeafHash(api, hFn, old_root, siblings, old_key, hash1_old, is_old0, new_key,
+                          hash1_new, fnc0, fnc1):
+    api.AssertIsBoolean(is_old0)
+    levels = len(siblings)
+    enabled = api.Sub(api.Add(fnc0, fnc1), api.Mul(fnc0, fnc1))
+    n2b_old = lowBits(api, old_key, levels)
+    n2b_new = lowBits(api, new_key, levels)
+    smt_lev_ins = LevIns(api, enabled, siblings)
+    xors = [api.Xor(n2b_old[i], n2b_new[i]) for i in range(levels)]
+    st = [None] * levels
+    for i in range(levels):
+        prev = (enabled, 0, 0, 0, api.Sub(1, enabled), 0) if i == 0 else st[i - 1]
+        st[i] = ProcessorSM(api, xors[i], is_old0, smt_lev_ins[i], fnc0, *prev)
+    top, old0, bot, new1, na, upd = st[levels - 1]
+    api.AssertIsEqual(api.Add(na, new1, old0, upd), 1)
+    lv_old, lv_new = [None] * levels, [None] * levels
+    for i in range(levels - 1, -1, -1):
+        top, old0, bot, new1, na, upd = st[i]
+        oc, nc = (0, 0) if i == levels - 1 else (lv_old[i + 1], lv_new[i + 1])
+        lv_old[i], lv_new[i] = ProcessorLevel(api, hFn, top, old0, bot, new1, upd, siblings[i],
+                                              hash1_old, hash1_new, n2b_new[i], oc, nc)
+    top_l, top_r = Switcher(api, api.Mul(fnc0, fnc1), lv_old[0], lv_new[0])
+    ForceEqualIfEnabled(api, old_root, top_l, enabled)
+    new_root = api.Add(api.Mul(enabled, api.Sub(top_r, old_root)), old_root)
+    are_key_equals = IsEqual(api, old_key, new_key)
+    keys_ok = MultiAnd(api, [api.Sub(1, fnc0), fnc1, api.Sub(1, are_key_equals)])
+    api.AssertIsEqual(keys_ok, 0)
+    return new_root
+
+
+def Processor(api, hFn, old_root, siblings, old_key, old_value, is_old0, new_key, new_value, fnc0,
+              fnc1):
+    hash1_old = Hash1(api, hFn, old_key, old_value)
+    hash1_new = Hash1(api, hFn, new_key, new_value)
+    return ProcessorWithLeafHash(api, hFn, old_root, siblings, old_key, hash1_old, is_old0,
+                                 new_key, hash1_new, fnc0, fnc1)

@@ -1,0 +1,201 @@
+"""ElGamal / BabyJubJub gadgets (config 4) and the SMT processor, against off-circuit arithmetic
+and the reference's hard-coded vectors."""
+import json
+import os
+import random
+
+import pytest
+
+from gnark_crypto_primitives_amd import circuits
+from gnark_crypto_primitives_amd.ecc import babyjub_native as bjj
+from gnark_crypto_primitives_amd.ecc import format as teformat
+from gnark_crypto_primitives_amd.elgamal import FixedBaseScalarMulBN254
+from gnark_crypto_primitives_amd.elgamal.mul import fixed_base_table
+from gnark_crypto_primitives_amd.frontend import Public, Secret, compile_circuit
+from gnark_crypto_primitives_amd.frontend.compile import from_mont_array, to_mont_array
+from gnark_crypto_primitives_amd.std.twistededwards import Curve, Point
+from gnark_crypto_primitives_amd.tree import smt
+from gnark_crypto_primitives_amd.utils import PoseidonHasher
+from oracle import cref, pyref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_native_curve_matches_oracle():
+    assert (bjj.A, bjj.D, bjj.BASE, bjj.ORDER) == (pyref.BJJ_A, pyref.BJJ_D, pyref.BJJ_BASE,
+                                                   pyref.BJJ_ORDER)
+    rng = random.Random(1)
+    for _ in range(5):
+        k = rng.randrange(bjj.ORDER)
+        assert bjj.mul(bjj.BASE, k) == pyref.bjj_mul(pyref.BJJ_BASE, k)
+    assert bjj.mul(bjj.BASE, bjj.ORDER) == bjj.IDENTITY
+    t = fixed_base_table()
+    assert len(t) == 64 and len(t[0]) == 16 and len(t[63]) == 4
+    assert t[5][7] == bjj.mul(bjj.BASE, 7 << 20)
+
+
+def test_format_k4():
+    """ecc/format/twistededwards.go:17-23: limb constants are -f and (-f)^-1; the iden3 base point
+    B8 maps to gnark's base; test point of twistededwards_test.go:71,73 round-trips."""
+    f = teformat.SCALING_FACTOR
+    limbs = lambda ls: sum(int(x) << (64 * i) for i, x in enumerate(ls))
+    assert limbs(["15521113859322357913", "12938262829174804345", "10076105873221699301",
+                  2473702300600416990]) == -f % pyref.R
+    assert limbs([2444430762821907778, "13992585508913553050", 6869659700585691715,
+                  304596441941759207]) == pow(-f % pyref.R, pyref.R - 2, pyref.R)
+    b8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553,
+          16950150798460657717958625567821834550301663161624707787222815936182638968203)
+    assert teformat.te_to_rte_native(*b8) == bjj.BASE
+
+    class Cc:
+        X = Secret()
+        Y = Secret()
+        XR = Public()
+
+        def define(self, api):
+            xr, yr = teformat.FromTEtoRTE(api, self.X, self.Y)
+            api.AssertIsEqual(xr, self.XR)
+            xt, _ = teformat.FromRTEtoTE(api, xr, yr)
+            api.AssertIsEqual(xt, self.X)
+    cc = compile_circuit(Cc())
+    cc.run_program(cc.assignment_vector({"X": b8[0], "Y": b8[1], "XR": bjj.BASE[0]}))
+    assert cc.last_status == 0
+
+
+def test_curve_gadget_vs_native():
+    class Cc:
+        P = Secret(2)
+        Q = Secret(2)
+        K = Secret()
+        Sum = Public(2)
+        Dbl = Public(2)
+        Mul = Public(2)
+        Fix = Public(2)
+
+        def define(self, api):
+            c = Curve(api)
+            p, q = Point(*self.P), Point(*self.Q)
+            c.AssertIsOnCurve(p)
+            for got, want in ((c.Add(p, q), self.Sum), (c.Double(p), self.Dbl),
+                              (c.ScalarMul(p, self.K), self.Mul),
+                              (FixedBaseScalarMulBN254(api, self.K), self.Fix)):
+                api.AssertIsEqual(got.X, want[0])
+                api.AssertIsEqual(got.Y, want[1])
+    cc = compile_circuit(Cc())
+    rh = cref.R1csHandle(cc)
+    rng = random.Random(3)
+    for k in (0, 1, 16, 0xf0, rng.randrange(bjj.ORDER), bjj.ORDER - 1):
+        p = bjj.mul(bjj.BASE, rng.randrange(1, bjj.ORDER))
+        q = bjj.mul(bjj.BASE, rng.randrange(1, bjj.ORDER))
+        asg = {"P": list(p), "Q": list(q), "K": k, "Sum": list(bjj.add(p, q)),
+               "Dbl": list(bjj.add(p, p)), "Mul": list(bjj.mul(p, k)),
+               "Fix": list(bjj.mul(bjj.BASE, k))}
+        inp = cc.assignment_vector(asg)
+        wires, *_ = cc.run_program(inp)
+        assert cc.last_status == 0 and cc.is_satisfied(wires)[0], k
+        rc, w2, *_ = cref.r1cs_solve(rh, to_mont_array(inp))
+        assert rc == 0 and from_mont_array(w2) == wires
+    asg["Mul"] = list(bjj.mul(p, k + 1))
+    cc.run_program(cc.assignment_vector(asg))
+    assert cc.last_status != 0
+
+
+def test_elgamal_add_config4():
+    cc = compile_circuit(circuits.ElGamalAddCircuit())
+    assert 14 <= cc.n_constraints <= 20 and cc.domain_log2() in (4, 5)   # SURVEY.md §8a estimate
+    rng = random.Random(2)
+    pub = bjj.mul(bjj.BASE, rng.randrange(bjj.ORDER))
+
+    def enc(m):
+        k = rng.randrange(bjj.ORDER)
+        return bjj.mul(bjj.BASE, k) + bjj.add(bjj.mul(bjj.BASE, m), bjj.mul(pub, k))
+    a, b = enc(3), enc(4)
+    s = bjj.add(a[:2], b[:2]) + bjj.add(a[2:], b[2:])
+    cc.run_program(cc.assignment_vector({"A": list(a), "B": list(b), "Sum": list(s)}))
+    assert cc.last_status == 0
+    cc.run_program(cc.assignment_vector({"A": list(a), "B": list(b), "Sum": list(a)}))
+    assert cc.last_status != 0
+
+
+def test_encrypt_circuit_reference_inputs():
+    """elgamal/encrypt_test.go:154-155: k = 12345, m = 67890, public key = base point."""
+    cc = compile_circuit(circuits.ElGamalEncryptCircuit())
+    assert 6000 < cc.n_constraints < 10000 and cc.domain_log2() == 13
+    k, m, pub = 12345, 67890, bjj.BASE
+    ex = bjj.mul(bjj.BASE, k) + bjj.add(bjj.mul(bjj.BASE, m), bjj.mul(pub, k))
+    asg = {"PubKey": list(pub), "Expected": list(ex), "K": k, "M": m}
+    wires, *_ = cc.run_program(cc.assignment_vector(asg))
+    assert cc.last_status == 0 and cc.is_satisfied(wires)[0]
+    asg["M"] = m + 1
+    cc.run_program(cc.assignment_vector(asg))
+    assert cc.last_status != 0
+
+
+def test_decryption_proof_k3_vector_and_invalid_a1y():
+    """elgamal/ciphertext_test.go:289-344: the hard-coded Chaum-Pedersen proof is accepted; the
+    same assignment with A1.Y = 0 is rejected."""
+    v = {k: int(x) for k, x in json.load(open(os.path.join(GOLD, "chaum_pedersen_k3.json"))).items()}
+    cc = compile_circuit(circuits.DecryptionProofCircuit())
+    asg = {"PubKey": [v["pubKeyX"], v["pubKeyY"]],
+           "Ct": [v["c1X"], v["c1Y"], v["c2X"], v["c2Y"]],
+           "A1": [v["mockA1X"], v["mockA1Y"]], "A2": [v["mockA2X"], v["mockA2Y"]],
+           "Z": v["mockZ"], "Msg": v["mockMsg"]}
+    inp = cc.assignment_vector(asg)
+    wires, *_ = cc.run_program(inp)
+    assert cc.last_status == 0 and cc.is_satisfied(wires)[0]
+    assert cref.r1cs_solve(cref.R1csHandle(cc), to_mont_array(inp))[0] == 0
+    bad = dict(asg, A1=[v["mockA1X"], 0])
+    cc.run_program(cc.assignment_vector(bad))
+    assert cc.last_status != 0
+
+
+def _processor_circuit(levels):
+    class Cc:
+        OldRoot = Secret()
+        Siblings = Secret(levels)
+        OldKey = Secret()
+        OldValue = Secret()
+        IsOld0 = Secret()
+        NewKey = Secret()
+        NewValue = Secret()
+        Fnc0 = Secret()
+        Fnc1 = Secret()
+        NewRoot = Secret()
+
+        def define(self, api):
+            h1o = smt.Hash1(api, PoseidonHasher, self.OldKey, self.OldValue)
+            h1n = smt.Hash1(api, PoseidonHasher, self.NewKey, self.NewValue)
+            nr = smt.ProcessorWithLeafHash(api, PoseidonHasher, self.OldRoot, self.Siblings,
+                                           self.OldKey, h1o, self.IsOld0, self.NewKey, h1n,
+                                           self.Fnc0, self.Fnc1)
+            api.AssertIsEqual(nr, self.NewRoot)
+    return Cc()
+
+
+def test_processor_k5_and_insert_update():
+    """tree/smt/processor_test.go:47-70: the all-zero assignment (fnc0 = fnc1 = 0) is valid,
+    IsOld0 = 2 is not.  Plus an insert into an empty tree and an update of that leaf."""
+    levels = 4
+    cc = compile_circuit(_processor_circuit(levels))
+    zero = dict(OldRoot=0, Siblings=[0] * levels, OldKey=0, OldValue=0, IsOld0=0, NewKey=0,
+                NewValue=0, Fnc0=0, Fnc1=0, NewRoot=0)
+    cc.run_program(cc.assignment_vector(zero))
+    assert cc.last_status == 0
+    cc.run_program(cc.assignment_vector(dict(zero, IsOld0=2)))
+    assert cc.last_status != 0
+    # insert (fnc = 1,0) key 5 -> value 9 into the empty tree: new root = H(5, 9, 1)
+    leaf = pyref.poseidon_hash([5, 9, 1])
+    ins = dict(zero, IsOld0=1, NewKey=5, NewValue=9, Fnc0=1, Fnc1=0, NewRoot=leaf)
+    cc.run_program(cc.assignment_vector(ins))
+    assert cc.last_status == 0
+    cc.run_program(cc.assignment_vector(dict(ins, NewRoot=leaf + 1)))
+    assert cc.last_status != 0
+    # update (fnc = 0,1) the same key to value 11
+    leaf2 = pyref.poseidon_hash([5, 11, 1])
+    upd = dict(zero, OldRoot=leaf, OldKey=5, OldValue=9, NewKey=5, NewValue=11, Fnc0=0, Fnc1=1,
+               NewRoot=leaf2)
+    cc.run_program(cc.assignment_vector(upd))
+    assert cc.last_status == 0
+    # update that changes the key must be rejected (keysOk guard)
+    cc.run_program(cc.assignment_vector(dict(upd, NewKey=6)))
+    assert cc.last_status != 0

@@ -152,3 +152,74 @@ def test_pipelined_submit_collect_matches_blocking(zk_ctx, poseidon_setup):
     with pytest.raises(lib.ZkmiError):
         prover.solve(batches[0][0])
     prover.collect()
+
+
+def _prove_and_check(zk_ctx, cc, assignments, seed, wbits=(7, 5)):
+    """prove a batch on the GPU and compare every proof with the C oracle."""
+    from oracle import cref
+    pk, vk, td = groth16.setup(cc, seed, groth16.gpu_mul(zk_ctx))
+    prover = groth16.Prover(zk_ctx, cc, pk, *wbits)
+    rng = random.Random(seed)
+    inp = np.stack([to_mont_array(cc.assignment_vector(a)) for a in assignments])
+    rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in assignments])
+    proofs, status = prover.prove(inp, rs)
+    want, wstatus, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk), inp, rs)
+    prover.close()
+    assert np.array_equal(status != 0, wstatus != 0)
+    ok = status == 0
+    assert np.array_equal(proofs[ok], want[ok])
+    return status
+
+
+def test_config3_verifier_inclusion_and_exclusion(zk_ctx):
+    """BASELINE config 3: smt.Verifier with fnc = 0 and fnc = 1 through one constraint system."""
+    levels = 10
+    cc = compile_circuit(circuits.smt_verifier_circuit(levels))
+    rng = random.Random(33)
+    asg = []
+    for i in range(12):
+        w = smt_witness.synthetic_inclusion(rng, levels, 3)
+        if i % 2 == 0:
+            asg.append(dict(w, OldKey=w["Key"], OldValue=w["Value"], IsOld0=0, Fnc=0))
+        else:
+            other = (w["Key"] & 0b111) | (((w["Key"] >> 3) ^ 1) << 3)
+            asg.append(dict(w, OldKey=w["Key"], OldValue=w["Value"], IsOld0=0, Key=other, Value=0,
+                            Fnc=1))
+    asg[5] = dict(asg[5], Key=asg[5]["OldKey"])      # excluded key is present -> unsatisfied
+    status = _prove_and_check(zk_ctx, cc, asg, 3)
+    assert list(status != 0) == [i == 5 for i in range(12)]
+
+
+def test_config4_elgamal_add(zk_ctx):
+    """BASELINE config 4: homomorphic add of two BabyJubJub ElGamal ciphertexts (domain 2^4)."""
+    from gnark_crypto_primitives_amd.ecc import babyjub_native as bjj
+    cc = compile_circuit(circuits.ElGamalAddCircuit())
+    rng = random.Random(4)
+    pub = bjj.mul(bjj.BASE, rng.randrange(bjj.ORDER))
+
+    def enc(m):
+        k = rng.randrange(bjj.ORDER)
+        return bjj.mul(bjj.BASE, k) + bjj.add(bjj.mul(bjj.BASE, m), bjj.mul(pub, k))
+    asg = []
+    for i in range(70):
+        a, b = enc(i), enc(1000 - i)
+        asg.append({"A": list(a), "B": list(b),
+                    "Sum": list(bjj.add(a[:2], b[:2]) + bjj.add(a[2:], b[2:]))})
+    asg[7]["Sum"][0] = (asg[7]["Sum"][0] + 1) % H.R
+    status = _prove_and_check(zk_ctx, cc, asg, 4, wbits=(6, 4))
+    assert list(status != 0) == [i == 7 for i in range(70)]
+
+
+def test_config4b_elgamal_encrypt(zk_ctx):
+    """Encrypt circuit (elgamal/encrypt_test.go:61-86): two fixed-base and one variable-base
+    scalar multiplication in-circuit, 7 232 constraints."""
+    from gnark_crypto_primitives_amd.ecc import babyjub_native as bjj
+    cc = compile_circuit(circuits.ElGamalEncryptCircuit())
+    rng = random.Random(44)
+    asg = []
+    for k, m in ((12345, 67890), (1, 0), (rng.randrange(bjj.ORDER), rng.getrandbits(60))):
+        pub = bjj.mul(bjj.BASE, rng.randrange(1, bjj.ORDER))
+        ex = bjj.mul(bjj.BASE, k) + bjj.add(bjj.mul(bjj.BASE, m), bjj.mul(pub, k))
+        asg.append({"PubKey": list(pub), "Expected": list(ex), "K": k, "M": m})
+    status = _prove_and_check(zk_ctx, cc, asg, 5)
+    assert not status.any()
