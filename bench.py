@@ -153,15 +153,30 @@ def main():
         alg_bytes = sum(n * 64 + B * n * 32 for n in ns)
         msm_s = stage[6] * 1e-3
         achieved = alg_bytes / msm_s / 1e9 if msm_s > 0 else 0.0
-        W = None
-        roofline = {"bound": "hbm", "kernel": "msm_accumulate<Fq> (G1)", "achieved": achieved,
-                    "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                    "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
-                    "algorithmic_bytes_per_step": alg_bytes}
-        # integer-ALU view of the same kernel: field products per second it sustains
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE +
+        # WRITE_SIZE of the four launches, raw counter values; same circuit, batch and windows)
+        traffic = None
         try:
-            peak_mul = ctx.field_mul_bench(1, 1 << 22, 256)
-            roofline["alu_peak_fq_mul_per_s"] = peak_mul
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if pm.get("batch") == B and pm.get("levels") == args.levels:
+                traffic = pm["msm_g1_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        roofline = {"bound": "hbm", "kernel": "msm_accumulate<Fq, false> (G1 MSMs of the key)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
+                    "algorithmic_bytes_per_launch": alg_bytes / 4.0}
+        # The kernel is bound by the integer multiplier, not HBM: report the
+        # v_mad_u64_u32 view beside the HBM one.  1563 mads per mixed addition (csrc/ec29.h),
+        # ceil(255/c) additions per (base, proof); peak 3.55e13 lane-mads/s measured by
+        # tools/instr_rate.hip (profiles/r01_instr_rate.log).
+        c1 = args.window_g1 or 10
+        madds = sum(ns) * ((255 + c1 - 1) // c1) * B
+        roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1563 / msm_s,
+                           "peak": 3.55e13, "frac": madds * 1563 / msm_s / 3.55e13}
+        try:
+            roofline["alu"]["fq_mul_per_s_ff29_microbench"] = ctx.field_mul_bench(2, 1 << 22, 256)
         except Exception:
             pass
         cpu = None

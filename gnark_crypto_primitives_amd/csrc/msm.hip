@@ -109,7 +109,9 @@ template <> struct Acc29<Fq2> {
   }
 };
 
-template <class F>
+// ONE_BASE only changes the symbol name: the one-base launches (delta multiples in the assembly,
+// zkmi_fixed_base_mul) then show up separately from the proving-key MSMs in rocprofv3 statistics.
+template <class F, bool ONE_BASE>
 __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restrict__ table,
                                                       const Fr* __restrict__ scalars,
                                                       const uint32_t* __restrict__ row_idx,
@@ -146,17 +148,22 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
   partial[(size_t)chunk * Bp + b] = to_std(acc);
 }
 
+// sums groups of `group` consecutive chunk partials: out[g][b] = sum_{k < group} in[g*group + k][b]
 template <class F>
 __global__ __launch_bounds__(64) void msm_reduce(const XYZZ<F>* __restrict__ partial, size_t Bp,
-                                                 uint32_t chunks, XYZZ<F>* __restrict__ out) {
+                                                 uint32_t chunks, uint32_t group,
+                                                 XYZZ<F>* __restrict__ out) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
-  XYZZ<F> acc = partial[b];
-  for (uint32_t k = 1; k < chunks; k++) {
+  const uint32_t k0 = blockIdx.y * group;
+  uint32_t k1 = k0 + group;
+  if (k1 > chunks) k1 = chunks;
+  XYZZ<F> acc = partial[(size_t)k0 * Bp + b];
+  for (uint32_t k = k0 + 1; k < k1; k++) {
     XYZZ<F> p = partial[(size_t)k * Bp + b];
     padd(acc, p);
   }
-  out[b] = acc;
+  out[(size_t)blockIdx.y * Bp + b] = acc;
 }
 
 template <class F>
@@ -260,20 +267,38 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   uint32_t per_chunk = (uint32_t)((n + chunks - 1) / chunks);
   chunks = (n + per_chunk - 1) / per_chunk;
   void* partial;
-  int rc = ensure_scratch(ctx, 6, chunks * Bp * sizeof(XYZZ<F>), &partial);
+  // partials + room for the intermediate level of the reduction
+  int rc = ensure_scratch(ctx, 6, (chunks + 64) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
   const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
-  const int ev = (ctx->msm_ev_on && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
+  const int ev = (ctx->msm_ev_on && n > 1 && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
   if (ev >= 0) {
     ctx->msm_ev_group[ev] = bases->group;
     hipEventRecord(ctx->msm_ev[ev][0], ctx->stream);
   }
-  hipLaunchKernelGGL((msm_accumulate<F>), dim3((unsigned)(Bp / bx), (unsigned)chunks), dim3(bx), 0,
-                     ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx, Bp,
-                     (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  if (n == 1)
+    hipLaunchKernelGGL((msm_accumulate<F, true>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
+                       dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
+                       Bp, (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+  else
+    hipLaunchKernelGGL((msm_accumulate<F, false>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
+                       dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
+                       Bp, (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
   if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
-  hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
-                     (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, out);
+  // two-level sum of the per-chunk partials (sqrt(chunks) groups) keeps the tail parallel
+  uint32_t group = 1;
+  while ((size_t)group * group < chunks) group++;
+  const uint32_t ngroups = (uint32_t)((chunks + group - 1) / group);
+  if (ngroups > 1) {
+    XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * Bp;
+    hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), ngroups), dim3(64), 0,
+                       ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid);
+    hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0, ctx->stream,
+                       (const XYZZ<F>*)mid, Bp, ngroups, ngroups, out);
+  } else {
+    hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0, ctx->stream,
+                       (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, (uint32_t)chunks, out);
+  }
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
 }
