@@ -1,4 +1,5 @@
 """The circuits BASELINE.json's configs name, as the reference's own tests define them."""
+from .ecc import eddsa
 from .elgamal import Ciphertext, DecryptionProof
 from .frontend import Public, Secret
 from .hash import poseidon
@@ -91,3 +92,16 @@ class DecryptionProofCircuit:
         proof = DecryptionProof(Point(*self.A1), Point(*self.A2), self.Z)
         proof.Verify(api, PoseidonMultiHasher, Point(*self.PubKey),
                      Ciphertext(Point(c[0], c[1]), Point(c[2], c[3])), self.Msg)
+
+
+class EdDSACircuit:
+    """testEdDSAVerifierCircuit shape (ecc/bn254/eddsa/verifier_test.go): Poseidon hasher."""
+    A = Public(2)
+    R = Public(2)
+    S = Public()
+    Msg = Public()
+
+    def define(self, api):
+        v = eddsa.NewVerifier(api, poseidon.Poseidon(api))
+        v.Verify(eddsa.PublicKey(Point(*self.A)), eddsa.Signature(Point(*self.R), self.S),
+                 self.Msg)

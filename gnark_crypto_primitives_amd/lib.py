@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+LIB_PATH = os.environ.get("ZKMI_LIB", os.path.join(_HERE, "libzkmi.so"))
 
 ZKMI_OK = 0
 ZKMI_ERR_UNSATISFIED = -5

@@ -41,3 +41,48 @@ if __name__ == "__main__":
     json.dump(chaum_pedersen(), open(os.path.join(HERE, "chaum_pedersen_k3.json"), "w"), indent=1)
     json.dump(poseidon(), open(os.path.join(HERE, "poseidon_kat.json"), "w"), indent=1)
     print("fixtures written")
+
+
+def groth16_regression():
+    """Self-regression fixture: seeded setup + (r, s) -> proof bytes, produced
+    by the C oracle for the single-Poseidon circuit (BASELINE config 1) and a 6-level SMT
+    inclusion circuit.  Guards both the oracle and the GPU path against silent drift."""
+    import random
+
+    import numpy as np
+
+    from gnark_crypto_primitives_amd import circuits, groth16
+    from gnark_crypto_primitives_amd.frontend import compile_circuit
+    from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+    from gnark_crypto_primitives_amd.tree import smt_witness
+    from oracle import cref
+    from tests import helpers as H
+    out = {}
+    mul = lambda g, s: cref.batch_mul(g, H.g1_gen_mont() if g == 1 else H.g2_gen_mont(), s)
+    for name, circuit, seed in (("poseidon", circuits.PoseidonCircuit(), 101),
+                                ("smt6", circuits.smt_inclusion_circuit(6), 102)):
+        cc = compile_circuit(circuit)
+        pk, _, _ = groth16.setup(cc, seed, mul)
+        rng = random.Random(seed)
+        if name == "poseidon":
+            datas = [rng.randrange(pyref.R) for _ in range(3)]
+            asg = [{"Data": d, "Hash": pyref.poseidon_hash([d])} for d in datas]
+        else:
+            asg = [smt_witness.synthetic_inclusion(rng, 6, k) for k in (0, 2, 5)]
+        inputs = [cc.assignment_vector(a) for a in asg]
+        rs = [[rng.randrange(pyref.R), rng.randrange(pyref.R)] for _ in asg]
+        proofs, status, _ = cref.groth16_prove_batch(
+            cref.R1csHandle(cc), cref.PkHandle(pk),
+            np.stack([to_mont_array(v) for v in inputs]), np.stack([to_mont_array(v) for v in rs]))
+        assert not status.any()
+        out[name] = {"setup_seed": seed, "fingerprint": cc.fingerprint(),
+                     "inputs": [[str(x) for x in v] for v in inputs],
+                     "rs": [[str(x) for x in v] for v in rs],
+                     "proofs_hex": [p.tobytes().hex() for p in proofs]}
+    return out
+
+
+if __name__ == "__main__":
+    json.dump(groth16_regression(), open(os.path.join(HERE, "groth16_regression.json"), "w"),
+              indent=1)
+    print("groth16 regression fixture written")

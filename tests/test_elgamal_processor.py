@@ -199,3 +199,26 @@ def test_processor_k5_and_insert_update():
     # update that changes the key must be rejected (keysOk guard)
     cc.run_program(cc.assignment_vector(dict(upd, NewKey=6)))
     assert cc.last_status != 0
+
+
+def test_eddsa_verifier():
+    """ecc/bn254/eddsa/verifier.go:55-94 against an off-circuit iden3-style signature."""
+    from gnark_crypto_primitives_amd.ecc import eddsa
+    from gnark_crypto_primitives_amd.hash import poseidon_native
+    cc = compile_circuit(circuits.EdDSACircuit())
+    rng = random.Random(6)
+    sk, nonce, msg = rng.randrange(bjj.ORDER), rng.randrange(bjj.ORDER), rng.randrange(pyref.R)
+    a, r8, S = eddsa.sign_native(sk, nonce, msg, poseidon_native.hash)
+    # the same relation off-circuit, in RTE coordinates, with the oracle's curve
+    ha = pyref.poseidon_hash([r8[0], r8[1], a[0], a[1], msg])
+    lhs = pyref.bjj_mul(pyref.BJJ_BASE, S)
+    rhs = pyref.bjj_add(teformat.te_to_rte_native(*r8),
+                        pyref.bjj_mul(teformat.te_to_rte_native(*a), 8 * ha))
+    assert lhs == rhs
+    asg = {"A": list(a), "R": list(r8), "S": S, "Msg": msg}
+    wires, *_ = cc.run_program(cc.assignment_vector(asg))
+    assert cc.last_status == 0 and cc.is_satisfied(wires)[0]
+    cc.run_program(cc.assignment_vector(dict(asg, Msg=(msg + 1) % pyref.R)))
+    assert cc.last_status != 0
+    cc.run_program(cc.assignment_vector(dict(asg, S=(S + 1) % bjj.ORDER)))
+    assert cc.last_status != 0

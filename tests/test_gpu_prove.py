@@ -223,3 +223,19 @@ def test_config4b_elgamal_encrypt(zk_ctx):
         asg.append({"PubKey": list(pub), "Expected": list(ex), "K": k, "M": m})
     status = _prove_and_check(zk_ctx, cc, asg, 5)
     assert not status.any()
+
+
+def test_groth16_regression_fixture_gpu(zk_ctx):
+    """GPU proofs equal the committed proof bytes of tests/golden/groth16_regression.json."""
+    from tests.test_oracle import _regression_cases
+    for name, circuit, fx in _regression_cases():
+        cc = compile_circuit(circuit)
+        assert cc.fingerprint() == fx["fingerprint"]
+        pk, _, _ = groth16.setup(cc, fx["setup_seed"], groth16.gpu_mul(zk_ctx))
+        prover = groth16.Prover(zk_ctx, cc, pk, 7, 5)
+        inp = np.stack([to_mont_array([int(x) for x in v]) for v in fx["inputs"]])
+        rs = np.stack([to_mont_array([int(x) for x in v]) for v in fx["rs"]])
+        proofs, status = prover.prove(inp, rs)
+        prover.close()
+        assert not status.any()
+        assert [p.tobytes().hex() for p in proofs] == fx["proofs_hex"]

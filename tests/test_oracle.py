@@ -144,3 +144,28 @@ def test_groth16_c_oracle_vs_closed_form_and_pairing():
     # different window sizes of the oracle's Pippenger give the same proof
     rc, proof2 = cref.groth16_prove(rh, ph, to_mont_array(inp), to_mont_array([r, s]), msm_c=4)
     assert rc == 0 and np.array_equal(proof, proof2)
+
+
+def _regression_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "groth16_regression.json")
+    fx = json.load(open(path))
+    for name, circuit in (("poseidon", circuits.PoseidonCircuit()),
+                          ("smt6", circuits.smt_inclusion_circuit(6))):
+        yield name, circuit, fx[name]
+
+
+def test_groth16_regression_fixture_oracle():
+    """Committed proof bytes (tests/golden/groth16_regression.json): same compile, same seeded
+    setup, same (r, s) -> byte-identical proofs from the C oracle."""
+    mul = lambda g, s: cref.batch_mul(g, H.g1_gen_mont() if g == 1 else H.g2_gen_mont(), s)
+    for name, circuit, fx in _regression_cases():
+        cc = compile_circuit(circuit)
+        assert cc.fingerprint() == fx["fingerprint"], "constraint system changed: regenerate"
+        pk, _, _ = groth16.setup(cc, fx["setup_seed"], mul)
+        inp = np.stack([to_mont_array([int(x) for x in v]) for v in fx["inputs"]])
+        rs = np.stack([to_mont_array([int(x) for x in v]) for v in fx["rs"]])
+        proofs, status, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk), inp, rs)
+        assert not status.any()
+        assert [p.tobytes().hex() for p in proofs] == fx["proofs_hex"]
