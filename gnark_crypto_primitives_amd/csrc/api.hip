@@ -496,6 +496,27 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
     ctx->err = "pk: n_z must equal 2^log_n - 1";
     return ZKMI_ERR_ARG;
   }
+  if (d->log_n < 1 || d->log_n > 28) {
+    ctx->err = "pk: log_n out of range [1,28]";
+    return ZKMI_ERR_ARG;
+  }
+  // every wire index is range-checked on the host before any kernel can use it as a row number
+  {
+    struct { const uint32_t* p; uint32_t n; const char* name; } idx[3] = {
+        {d->a_wire, d->n_a, "a_wire"}, {d->b_wire, d->n_b, "b_wire"}, {d->k_wire, d->n_k, "k_wire"}};
+    for (auto& t : idx) {
+      std::vector<uint32_t> host(t.n);
+      if (t.n && hipMemcpy(host.data(), t.p, (size_t)t.n * 4, hipMemcpyDefault) != hipSuccess) {
+        ctx->err = std::string("pk: cannot read ") + t.name;
+        return ZKMI_ERR_HIP;
+      }
+      for (uint32_t i = 0; i < t.n; i++)
+        if (host[i] >= d->n_wires) {
+          ctx->err = std::string("pk: ") + t.name + " holds a wire index >= n_wires";
+          return ZKMI_ERR_ARG;
+        }
+    }
+  }
   auto* pk = new zkmi_pk();
   pk->log_n = d->log_n;
   pk->n_wires = d->n_wires;
