@@ -180,7 +180,7 @@ def main():
         except Exception:
             pass
         cpu = None
-        if args.cpu_sample != 0:
+        if args.cpu_sample != 0 and world == 1:      # CPU baseline: rank 0 at N = 1 only
             from oracle import cref
             cores = available_cpus()
             S = args.cpu_sample if args.cpu_sample > 0 else min(B, 2 * cores)
