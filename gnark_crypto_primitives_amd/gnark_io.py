@@ -1,0 +1,195 @@
+"""gnark / gnark-crypto wire formats for the artefacts that cross the prover boundary
+(first slice): group-element encodings, the Groth16 proof, the witness vector.
+
+Everything here restates upstream formats from memory [UPSTREAM-RECALL]: gnark-crypto's bn254
+``G1Affine.Bytes/RawBytes`` and ``G2Affine.Bytes/RawBytes`` (marshal.go), gnark's groth16 bn254
+``Proof.WriteTo/WriteRawTo`` and ``witness.WriteTo``.  No gnark build exists offline to confirm
+them; the tests check internal consistency (round trips, flag semantics, sizes).
+
+Encoding rules restated:
+* field elements are written big-endian, canonical (non-Montgomery) form, 32 bytes;
+* a compressed G1 point is X (32 B) with the two most significant bits of the first byte as flags:
+  0b10 = compressed, Y is the lexicographically smallest root; 0b11 = compressed, largest root;
+  0b01 = point at infinity; 0b00 = uncompressed (X || Y, 64 B);
+* a G2 point writes X.A1 then X.A0 (then Y.A1, Y.A0 when uncompressed); "largest" compares A1
+  first, then A0;
+* Proof.WriteTo = Ar (compressed) | Bs (compressed) | Krs (compressed) | uint32 number of
+  commitments (0 here) ... = 128 + 4 bytes (+ commitment PoK when present);
+  Proof.WriteRawTo uses the uncompressed forms: 64 + 128 + 64 + 4;
+* witness.WriteTo = uint32 nbPublic | uint32 nbSecret | uint32 length | length x 32-byte elements.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .frontend.compile import array_to_ints, ints_to_array
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+_MONT = (1 << 256) % P
+_MONT_INV = pow(_MONT, P - 2, P)
+_MONT_R = (1 << 256) % R
+_MONT_R_INV = pow(_MONT_R, R - 2, R)
+
+M_UNCOMPRESSED, M_INFINITY, M_SMALLEST, M_LARGEST = 0b00 << 6, 0b01 << 6, 0b10 << 6, 0b11 << 6
+
+
+def _fq_plain(limbs4):          # Montgomery limbs -> int
+    return array_to_ints(np.asarray(limbs4, dtype=np.uint64).reshape(1, 4))[0] * _MONT_INV % P
+
+
+def _fq_mont(x):
+    return ints_to_array([x % P * _MONT % P])[0]
+
+
+def _sqrt_fp(a):
+    # p = 3 mod 4
+    r = pow(a, (P + 1) // 4, P)
+    return r if r * r % P == a % P else None
+
+
+def _f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def _f2_sqrt(a):
+    """square root in Fp2 = Fp[u]/(u^2+1) (complex method), or None"""
+    a0, a1 = a
+    if a1 == 0:
+        r = _sqrt_fp(a0)
+        if r is not None:
+            return (r, 0)
+        r = _sqrt_fp(-a0 % P)
+        return (0, r) if r is not None else None
+    n = _sqrt_fp((a0 * a0 + a1 * a1) % P)
+    if n is None:
+        return None
+    for s in (n, -n % P):
+        t = (a0 + s) * pow(2, P - 2, P) % P
+        x0 = _sqrt_fp(t)
+        if x0 is not None and x0 != 0:
+            x1 = a1 * pow(2 * x0, P - 2, P) % P
+            if _f2_mul((x0, x1), (x0, x1)) == (a0 % P, a1 % P):
+                return (x0, x1)
+    return None
+
+
+_B2 = _f2_mul((3, 0), (lambda d: (9 * d % P, -d % P))(pow(82, P - 2, P)))   # 3 / (9 + u)
+
+
+def _lex_largest_fp(y):
+    return y > (P - 1) // 2
+
+
+def _lex_largest_fp2(y):
+    return _lex_largest_fp(y[1]) if y[1] != 0 else _lex_largest_fp(y[0])
+
+
+# ---- G1 ------------------------------------------------------------------------------------------
+def g1_to_bytes(pt_mont, compressed=True) -> bytes:
+    """pt_mont: 8 uint64 (X, Y Montgomery limbs), all zero = infinity."""
+    a = np.asarray(pt_mont, dtype=np.uint64).reshape(8)
+    size = 32 if compressed else 64
+    if not a.any():
+        return bytes([M_INFINITY]) + bytes(size - 1)
+    x, y = _fq_plain(a[:4]), _fq_plain(a[4:])
+    xb = bytearray(x.to_bytes(32, "big"))
+    if not compressed:
+        return bytes(xb) + y.to_bytes(32, "big")
+    xb[0] |= M_LARGEST if _lex_largest_fp(y) else M_SMALLEST
+    return bytes(xb)
+
+
+def g1_from_bytes(buf: bytes) -> np.ndarray:
+    flag = buf[0] & 0xC0
+    if flag == M_INFINITY:
+        return np.zeros(8, dtype=np.uint64)
+    x = int.from_bytes(bytes([buf[0] & 0x3F]) + buf[1:32], "big")
+    if flag == M_UNCOMPRESSED:
+        y = int.from_bytes(buf[32:64], "big")
+    else:
+        y = _sqrt_fp((x * x * x + 3) % P)
+        if y is None:
+            raise ValueError("x is not on the curve")
+        if _lex_largest_fp(y) != (flag == M_LARGEST):
+            y = P - y
+    return np.concatenate([_fq_mont(x), _fq_mont(y)])
+
+
+# ---- G2 ------------------------------------------------------------------------------------------
+def g2_to_bytes(pt_mont, compressed=True) -> bytes:
+    a = np.asarray(pt_mont, dtype=np.uint64).reshape(16)
+    size = 64 if compressed else 128
+    if not a.any():
+        return bytes([M_INFINITY]) + bytes(size - 1)
+    x0, x1, y0, y1 = (_fq_plain(a[4 * i:4 * i + 4]) for i in range(4))
+    xb = bytearray(x1.to_bytes(32, "big") + x0.to_bytes(32, "big"))
+    if not compressed:
+        return bytes(xb) + y1.to_bytes(32, "big") + y0.to_bytes(32, "big")
+    xb[0] |= M_LARGEST if _lex_largest_fp2((y0, y1)) else M_SMALLEST
+    return bytes(xb)
+
+
+def g2_from_bytes(buf: bytes) -> np.ndarray:
+    flag = buf[0] & 0xC0
+    if flag == M_INFINITY:
+        return np.zeros(16, dtype=np.uint64)
+    x1 = int.from_bytes(bytes([buf[0] & 0x3F]) + buf[1:32], "big")
+    x0 = int.from_bytes(buf[32:64], "big")
+    if flag == M_UNCOMPRESSED:
+        y1, y0 = int.from_bytes(buf[64:96], "big"), int.from_bytes(buf[96:128], "big")
+    else:
+        x = (x0, x1)
+        rhs = _f2_mul(_f2_mul(x, x), x)
+        rhs = ((rhs[0] + _B2[0]) % P, (rhs[1] + _B2[1]) % P)
+        y = _f2_sqrt(rhs)
+        if y is None:
+            raise ValueError("x is not on the twist")
+        if _lex_largest_fp2(y) != (flag == M_LARGEST):
+            y = (-y[0] % P, -y[1] % P)
+        y0, y1 = y
+    return np.concatenate([_fq_mont(v) for v in (x0, x1, y0, y1)])
+
+
+# ---- Groth16 proof ---------------------------------------------------------------------------------
+def proof_to_bytes(proof32, raw=False) -> bytes:
+    """proof32: the 32-word record of zkmi_prove_batch (Ar | Krs | Bs).  gnark writes Ar, Bs, Krs."""
+    a = np.asarray(proof32, dtype=np.uint64).reshape(32)
+    ar, krs, bs = a[0:8], a[8:16], a[16:32]
+    out = g1_to_bytes(ar, not raw) + g2_to_bytes(bs, not raw) + g1_to_bytes(krs, not raw)
+    return out + struct.pack(">I", 0)          # no commitments
+
+
+def proof_from_bytes(buf: bytes) -> np.ndarray:
+    raw = len(buf) >= 64 + 128 + 64
+    g1n, g2n = (64, 128) if raw else (32, 64)
+    ar = g1_from_bytes(buf[:g1n])
+    bs = g2_from_bytes(buf[g1n:g1n + g2n])
+    krs = g1_from_bytes(buf[g1n + g2n:2 * g1n + g2n])
+    return np.concatenate([ar, krs, bs])
+
+
+# ---- witness -----------------------------------------------------------------------------------------
+def witness_to_bytes(values, n_public: int) -> bytes:
+    """values: ints, public (without the ONE wire) then secret."""
+    values = [int(v) % R for v in values]
+    head = struct.pack(">III", n_public, len(values) - n_public, len(values))
+    return head + b"".join(v.to_bytes(32, "big") for v in values)
+
+
+def witness_from_bytes(buf: bytes):
+    n_pub, n_sec, n = struct.unpack(">III", buf[:12])
+    if n != n_pub + n_sec or len(buf) != 12 + 32 * n:
+        raise ValueError("malformed witness")
+    vals = [int.from_bytes(buf[12 + 32 * i:44 + 32 * i], "big") for i in range(n)]
+    if any(v >= R for v in vals):
+        raise ValueError("witness element not reduced")
+    return vals, n_pub
+
+
+def witness_to_inputs(buf: bytes) -> np.ndarray:
+    """witness bytes -> [n_inputs, 4] Montgomery limbs for Prover.prove"""
+    vals, _ = witness_from_bytes(buf)
+    return ints_to_array([v * _MONT_R % R for v in vals])
