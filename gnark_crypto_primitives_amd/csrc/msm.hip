@@ -175,12 +175,13 @@ __global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __res
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 20 %
-// for its G2 bases (Arbo-160 on a 288 GB MI355X: c = 10 for both).
+// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 30 %
+// for its G2 bases (Arbo-160 on a 288 GiB MI355X: c = 10 -> 147 GB for G1, c = 11 -> 85 GB for
+// G2; the working set of the pipeline is ~20 GB).
 int default_window(size_t n, int group) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  const double budget = (group == 1 ? 0.60 : 0.20) * (double)free_b;
+  const double budget = (group == 1 ? 0.60 : 0.30) * (double)free_b;
   const double entry = group == 1 ? 64.0 : 128.0;
   int best = 4;
   for (int c = 4; c <= 12; c++) {
