@@ -2,8 +2,6 @@
 // together: solve -> quotient (7 NTTs) -> 4 G1 MSMs + 1 G2 MSM -> assembly.
 // Stands in for groth16.Prove in gnark backend/groth16/bn254/prove.go [UPSTREAM-RECALL,
 // SURVEY.md §3.2].  There is no CPU fallback anywhere in this file.
-#include <mutex>
-
 #include "zkmi_internal.h"
 #include "ff29.h"
 

@@ -151,9 +151,10 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
                       size_t batch, const void* rs);
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
 
-/* Per-stage device time of the last zkmi_prove_batch, milliseconds, measured with HIP events on
- * the context's stream: [0] solve, [1] quotient (NTTs + pointwise), [2] G1 MSMs, [3] G2 MSM,
- * [4] assembly, [5] quotient..assembly total (the solve overlaps the previous batch), [6] sum over the four G1 msm_accumulate kernel launches alone (event
+/* Per-stage device time of the last zkmi_prove_collect / zkmi_prove_batch in milliseconds, from
+ * HIP events on the library's streams: [0] solve (stage 1, second stream), [1] quotient (NTTs +
+ * pointwise), [2] G1 MSMs, [3] G2 MSM, [4] assembly, [5] stage 2 total = [1]..[4] (the solve
+ * overlaps the previous batch), [6] sum over the four G1 msm_accumulate launches alone (one event
  * pair around each launch), [7] the G2 msm_accumulate launch alone. */
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out /* 8 doubles */);
 
