@@ -246,6 +246,9 @@ void zkmi_destroy(zkmi_ctx* ctx) {
     hipFree(p.tw_inv);
     hipFree(p.coset_fwd);
     hipFree(p.coset_inv);
+    hipFree(p.tw29_fwd);
+    hipFree(p.tw29_inv);
+    hipFree(p.coset29_fwd);
   }
   for (auto& s : ctx->scratch)
     if (s.p) hipFree(s.p);

@@ -54,6 +54,37 @@ struct Fq29Params {
   typedef FqParams Std;
 };
 
+// The scalar field r in the same form (used by the quotient NTTs, ntt.hip)
+struct Fr29Params {
+  static ZK_HD int32_t p(int i) {
+    constexpr int32_t v[9] = {0x10000001, 0x1f0fac9f, 0x0e5c2450, 0x07d090f3, 0x1585d283,
+                              0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e};
+    return v[i];
+  }
+  static constexpr uint32_t inv = 0x0fffffffu;  // -r^-1 mod 2^29
+  static ZK_HD int32_t one(int i) {             // 2^261 mod r
+    constexpr int32_t v[9] = {0x0fffff57, 0x1ea70ab4, 0x052c068b, 0x17504f49, 0x0aa8075b,
+                              0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836};
+    return v[i];
+  }
+  static ZK_HD int32_t c256(int i) {  // 2^256 mod r
+    constexpr int32_t v[9] = {0x0ffffffb, 0x04b1a0e2, 0x18334a6b, 0x18ed2b3e, 0x1462e36f,
+                              0x11b7bc3c, 0x1cbd99ba, 0x183340fb, 0x000e0a77};
+    return v[i];
+  }
+  static ZK_HD int32_t c266(int i) {  // 2^266 mod r
+    constexpr int32_t v[9] = {0x0fffead7, 0x1d5444f4, 0x04438aa5, 0x03b4d096, 0x134c84da,
+                              0x0e92d304, 0x14cb95b3, 0x041b9d3d, 0x00058003};
+    return v[i];
+  }
+  static ZK_HD uint32_t k261(int i) {  // 2^261 mod r as a plain 8 x u32 integer
+    constexpr uint32_t v[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u,
+                               0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};
+    return v[i];
+  }
+  typedef FrParams Std;
+};
+
 template <class P>
 struct F29 {
   int32_t v[9];
@@ -318,6 +349,7 @@ ZK_HD F29<P> wred(const F29<P>& a) {
 }
 
 typedef F29<Fq29Params> Fq29;
+typedef F29<Fr29Params> Fr29;
 
 // ---- Fq2 = Fq[u]/(u^2+1) on the lazy representation -----------------------------------------
 // Components are kept normalised; products use one shared reduction per component.

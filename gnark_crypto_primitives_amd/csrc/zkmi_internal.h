@@ -34,6 +34,12 @@ struct NttPlan {
   Fr* coset_inv = nullptr;  // g^-i / n, n
   Fr n_inv;                 // 1/n
   Fr den;                   // 1/(g^n - 1)
+  // the same constants in the 2^261 Montgomery domain of ff29.h (canonical, packed 8 x u32)
+  Fr* tw29_fwd = nullptr;
+  Fr* tw29_inv = nullptr;
+  Fr* coset29_fwd = nullptr;
+  Fr n_inv29;
+  Fr den29;
 };
 
 }  // namespace zk

@@ -135,6 +135,24 @@ int main() {
       }
     }
   }
+  // ---- the scalar field in the same representation (quotient NTTs)
+  for (int it = 0; it < 5000; it++) {
+    Fr x, y, z;
+    for (int i = 0; i < 8; i++) { x.v[i] = (uint32_t)rng(); y.v[i] = (uint32_t)rng(); z.v[i] = (uint32_t)rng(); }
+    x.v[7] &= 0x0fffffff; y.v[7] &= 0x0fffffff; z.v[7] &= 0x0fffffff;
+    Fr29 X = from_std<Fr29Params>(x), Y = from_std<Fr29Params>(y), Z = from_std<Fr29Params>(z);
+    CHECK(to_std(X) == x);
+    CHECK(to_std(mul(X, Y)) == mul(x, y));
+    CHECK(to_std(mul(sub(X, Y), Z)) == mul(sub(x, y), z));
+    CHECK(to_std(wred(add(add(sub(X, Y), Z), add(X, X)))) == add(add(sub(x, y), z), dbl(x)));
+    Fr k;
+    for (int i = 0; i < 8; i++) k.v[i] = Fr29Params::k261(i);
+    Fr xf = mul(x, k);                                  // canonical F-domain image of x
+    CHECK(to_std(unpack29<Fr29Params>(xf.v)) == x);
+    Fr packed;
+    pack_canonical<Fr29Params>(packed.v, wred(add(X, Y)));
+    CHECK(packed == mul(add(x, y), k));
+  }
   printf(fails ? "ff29 tests FAILED (%d)\n" : "ff29 tests ok\n", fails);
   return fails != 0;
 }
