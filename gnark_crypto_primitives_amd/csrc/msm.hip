@@ -22,6 +22,8 @@
 // integer ALU (v_mad_u64_u32), not HBM; both fractions are reported by bench.py.
 //
 // Algorithmic bytes per launch: n * sizeof(affine) + batch * n * 32.
+#include <cstdlib>
+
 #include "zkmi_internal.h"
 #include "ec29.h"
 
@@ -261,15 +263,24 @@ template <class F>
 static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
                     const uint32_t* row_idx, size_t Bp, XYZZ<F>* out) {
   const size_t n = bases->n;
-  // enough chunks for ~4 waves per SIMD over the whole chip
-  size_t chunks = (size_t)262144 / Bp;
+  // 8 x as many chunks as it takes to put 4 waves on every SIMD: all blocks of the coarse grid
+  // run for the whole kernel, so a few occupied wave slots (the overlapped solve of the next
+  // batch) or uneven clocks cost a full extra round; measured per 1024-proof batch, G1 launches:
+  // x1 325 ms, x2 315, x4 299, x8 292 (best end to end), x16 289 + dearer reduction.
+  // ZKMI_MSM_CHUNKS overrides.
+  static const size_t chunk_factor = [] {
+    const char* e = getenv("ZKMI_MSM_CHUNKS");
+    const long v = e ? atol(e) : 8;
+    return (size_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+  }();
+  size_t chunks = chunk_factor * (size_t)262144 / Bp;
   if (chunks < 1) chunks = 1;
   if (chunks > n) chunks = n;
   uint32_t per_chunk = (uint32_t)((n + chunks - 1) / chunks);
   chunks = (n + per_chunk - 1) / per_chunk;
   void* partial;
   // partials + room for the intermediate level of the reduction
-  int rc = ensure_scratch(ctx, 6, (chunks + 64) * Bp * sizeof(XYZZ<F>), &partial);
+  int rc = ensure_scratch(ctx, 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
   const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
   const int ev = (ctx->msm_ev_on && n > 1 && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
