@@ -168,13 +168,13 @@ def main():
                     "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
                     "algorithmic_bytes_per_launch": alg_bytes / 4.0}
         # The kernel is bound by the integer multiplier, not HBM: report the
-        # v_mad_u64_u32 view beside the HBM one.  1563 mads per mixed addition (csrc/ec29.h),
-        # ceil(255/c) additions per (base, proof); peak 3.55e13 lane-mads/s measured by
+        # v_mad_u64_u32 view beside the HBM one.  1548 mads per mixed addition (csrc/ec29.h), one
+        # addition per (base, window, proof); peak 3.55e13 lane-mads/s measured by
         # tools/instr_rate.hip (profiles/r01_instr_rate.log).
-        c1 = args.window_g1 or 10
-        madds = sum(ns) * ((255 + c1 - 1) // c1) * B
-        roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1563 / msm_s,
-                           "peak": 3.55e13, "frac": madds * 1563 / msm_s / 3.55e13}
+        info = ctx.pk_info(prover.pk_h)
+        madds = sum(ns) * info["g1_windows"] * B
+        roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1548 / msm_s,
+                           "peak": 3.55e13, "frac": madds * 1548 / msm_s / 3.55e13}
         try:
             roofline["alu"]["fq_mul_per_s_ff29_microbench"] = ctx.field_mul_bench(2, 1 << 22, 256)
         except Exception:
@@ -205,6 +205,7 @@ def main():
                        "constraints": cc.n_constraints, "wires": cc.n_wires,
                        "domain_log2": pk.log_n, "batch_per_gpu": B,
                        "msm_terms_per_proof": {"g1": int(sum(ns)), "g2": ns[1]},
+                       "msm_window_tables": ctx.pk_info(prover.pk_h),
                        "parallelism": f"batch-split x{world}, no collective"},
             "pipelined": not args.no_pipeline,
             "stage_ms": {"solve": stage[0], "quotient_7ntt": stage[1], "msm_g1": stage[2],

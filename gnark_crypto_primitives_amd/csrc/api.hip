@@ -382,14 +382,32 @@ int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, voi
   return ZKMI_OK;
 }
 
+// window_bits: 0 = as many bits per window as the table budget allows (windows of mixed width
+// summing to exactly 255 bits); 2..16 = uniform windows of that width.  If the table cannot be
+// allocated the plan is relaxed (more, narrower windows) until it fits.
+static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, WinPlan plan,
+                           bool may_relax, zkmi_msm_bases** out) {
+  for (;;) {
+    int rc = msm_bases_build(ctx, group, bases_dev, n, plan, out);
+    if (rc != ZKMI_ERR_OOM || !may_relax || plan.W >= 64) return rc;
+    plan = plan_with_windows(plan.W + 1);
+  }
+}
+
 int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
                         zkmi_msm_bases** out) {
   ZK_HIP(hipSetDevice(ctx->device));
   if (!out) return ZKMI_ERR_ARG;
+  if (window_bits != 0 && (window_bits < 2 || window_bits > 16)) {
+    ctx->err = "window_bits must be 0 (auto) or in [2,16]";
+    return ZKMI_ERR_ARG;
+  }
   Staged sb(ctx);
   int rc = sb.in(bases, n * (group == 1 ? 64 : 128));
   if (rc) return rc;
-  return msm_bases_build(ctx, group, sb.dev, n, window_bits, out);
+  const WinPlan plan = window_bits ? plan_uniform(window_bits)
+                                   : plan_windows_for_budget(n, group, table_budget(group));
+  return bases_load_plan(ctx, group, sb.dev, n, plan, window_bits == 0, out);
 }
 
 void zkmi_msm_bases_free(zkmi_ctx* ctx, zkmi_msm_bases* b) {
@@ -526,19 +544,28 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   pk->n_k = d->n_k;
   pk->n_z = d->n_z;
   int rc;
-  // one window size per group for the whole key, sized against free HBM
-  const int c1 = d->window_bits_g1
-                     ? (int)d->window_bits_g1
-                     : default_window((size_t)d->n_a + d->n_b + d->n_k + d->n_z, 1);
-  const int c2 = d->window_bits_g2 ? (int)d->window_bits_g2 : default_window(d->n_b, 2);
+  // one window plan per group for the whole key, sized against free HBM
+  const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
+  const WinPlan p1 = auto1 ? plan_windows_for_budget((size_t)d->n_a + d->n_b + d->n_k + d->n_z, 1,
+                                                     table_budget(1))
+                           : plan_uniform((int)d->window_bits_g1);
+  const WinPlan p2 = auto2 ? plan_windows_for_budget(d->n_b, 2, table_budget(2))
+                           : plan_uniform((int)d->window_bits_g2);
+  auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
+                  zkmi_msm_bases** out) -> int {
+    Staged sb(ctx);
+    int r = sb.in(pts, n * (group == 1 ? 64 : 128));
+    if (r) return r;
+    return bases_load_plan(ctx, group, sb.dev, n, plan, relax, out);
+  };
   if ((rc = upload_u32(ctx, d->a_wire, d->n_a, &pk->a_wire)) ||
       (rc = upload_u32(ctx, d->b_wire, d->n_b, &pk->b_wire)) ||
       (rc = upload_u32(ctx, d->k_wire, d->n_k, &pk->k_wire)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_a, d->n_a, c1, &pk->A)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_b, d->n_b, c1, &pk->B1)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_k, d->n_k, c1, &pk->K)) ||
-      (rc = zkmi_msm_bases_load(ctx, 1, d->g1_z, d->n_z, c1, &pk->Z)) ||
-      (rc = zkmi_msm_bases_load(ctx, 2, d->g2_b, d->n_b, c2, &pk->B2))) {
+      (rc = load(1, d->g1_a, d->n_a, p1, auto1, &pk->A)) ||
+      (rc = load(1, d->g1_b, d->n_b, p1, auto1, &pk->B1)) ||
+      (rc = load(1, d->g1_k, d->n_k, p1, auto1, &pk->K)) ||
+      (rc = load(1, d->g1_z, d->n_z, p1, auto1, &pk->Z)) ||
+      (rc = load(2, d->g2_b, d->n_b, p2, auto2, &pk->B2))) {
     zkmi_pk_free(ctx, pk);
     return rc;
   }
@@ -557,6 +584,17 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   hipMemcpy(&pk->beta2, d->g2_beta, 128, hipMemcpyDefault);
   hipMemcpy(&pk->delta2, d->g2_delta, 128, hipMemcpyDefault);
   *out = pk;
+  return ZKMI_OK;
+}
+
+int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info) {
+  if (!pk || !info) return ZKMI_ERR_ARG;
+  info[0] = (uint64_t)pk->Z->plan.W;
+  info[1] = pk->Z->plan.per_base;
+  info[2] = (uint64_t)pk->B2->plan.W;
+  info[3] = pk->B2->plan.per_base;
+  info[4] = pk->A->table_bytes + pk->B1->table_bytes + pk->K->table_bytes + pk->Z->table_bytes;
+  info[5] = pk->B2->table_bytes;
   return ZKMI_OK;
 }
 

@@ -40,23 +40,26 @@ ZK_HD Fq2 to_r261_domain(const Fq2& x) { return Fq2{to_r261_domain(x.c0), to_r26
 // ---- table construction ------------------------------------------------------------------------
 // One thread per base, windows in sequence.  Per window: D = 2^(c-1) running mixed additions into
 // XYZZ, then one Montgomery batch inversion over the D denominators (scratch is interleaved across
-// threads so lanes touch adjacent addresses), then 2^c * Q for the next window.
+// threads so lanes touch adjacent addresses), then 2^c * Q for the next window (c = that window's
+// width, WinPlan).
 template <class F>
 __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restrict__ bases,
-                                                      uint32_t i0, uint32_t n, int c, int W,
+                                                      uint32_t i0, uint32_t n, WinPlan plan,
                                                       Affine<F>* __restrict__ table,
                                                       F* __restrict__ scratch, uint32_t T,
                                                       int to_r261) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = i0 + t;
   if (t >= T || i >= n) return;
-  const uint32_t D = 1u << (c - 1);
+  const int W = plan.W;
+  const uint32_t Dmax = 1u << (plan.bits[0] - 1);   // the widest windows come first
   F* szz = scratch + t;
-  F* szzz = scratch + (size_t)D * T + t;
-  F* spre = scratch + (size_t)2 * D * T + t;
+  F* szzz = scratch + (size_t)Dmax * T + t;
+  F* spre = scratch + (size_t)2 * Dmax * T + t;
   Affine<F> Q = bases[i];
   for (int j = 0; j < W; j++) {
-    Affine<F>* row = table + (((size_t)i * W + j) << (c - 1));
+    const uint32_t D = 1u << (plan.bits[j] - 1);
+    Affine<F>* row = table + (size_t)i * plan.per_base + plan.off[j];
     if (Q.is_inf()) {
       for (uint32_t d = 0; d < D; d++) row[d] = Affine<F>::inf();
       continue;
@@ -118,22 +121,24 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
                                                       const Fr* __restrict__ scalars,
                                                       const uint32_t* __restrict__ row_idx,
                                                       size_t Bp, uint32_t n, uint32_t per_chunk,
-                                                      int c, int W, XYZZ<F>* __restrict__ partial) {
+                                                      WinPlan plan, XYZZ<F>* __restrict__ partial) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t chunk = blockIdx.y;
   const uint32_t i0 = chunk * per_chunk;
   uint32_t i1 = i0 + per_chunk;
   if (i1 > n) i1 = n;
-  const uint32_t mask = (1u << c) - 1u;
-  const uint32_t half = 1u << (c - 1);
+  const int W = plan.W;
   typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t i = i0; i < i1; i++) {
     const uint32_t row = row_idx ? row_idx[i] : i;
     Fr s = from_mont(bi_ld(scalars, row, b, Bp));
     if (s.is_zero()) continue;
-    const Affine<F>* trow = table + (((size_t)i * W) << (c - 1));
+    const Affine<F>* trow = table + (size_t)i * plan.per_base;
     uint32_t carry = 0;
     for (int j = 0; j < W; j++) {
+      const int c = plan.bits[j];                 // wave-uniform
+      const uint32_t mask = (1u << c) - 1u;
+      const uint32_t half = 1u << (c - 1);
       uint32_t d = (s.v[0] & mask) + carry;
 #pragma unroll
       for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> c) | (s.v[l + 1] << (32 - c));
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
       carry = negd ? 1u : 0u;
       const uint32_t mag = negd ? (mask + 1u - d) : d;
       if (mag) {
-        const Affine<F> e = trow[((size_t)j << (c - 1)) + (mag - 1)];
+        const Affine<F> e = trow[plan.off[j] + (mag - 1)];
         Acc29<F>::add(acc, e, negd);
       }
     }
@@ -177,27 +182,57 @@ __global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __res
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-// Largest window whose table fits the budget: 60 % of free HBM for the G1 bases of a key, 30 %
-// for its G2 bases (Arbo-160 on a 288 GiB MI355X: c = 10 -> 147 GB for G1, c = 11 -> 85 GB for
-// G2; the working set of the pipeline is ~20 GB).
-int default_window(size_t n, int group) {
+// ---- window plans ----------------------------------------------------------------------------------
+WinPlan plan_with_windows(int W) {
+  WinPlan p;
+  if (W < 16) W = 16;     // 16-bit windows at most
+  if (W > 64) W = 64;
+  p.W = W;
+  const int c0 = 255 / W, rem = 255 - c0 * W;
+  uint32_t off = 0;
+  for (int j = 0; j < W; j++) {
+    p.bits[j] = (uint8_t)(j < rem ? c0 + 1 : c0);
+    p.off[j] = off;
+    off += 1u << (p.bits[j] - 1);
+  }
+  p.per_base = off;
+  return p;
+}
+WinPlan plan_uniform(int c) {   // ceil(255 / c) windows of c bits (covers >= 255 bits)
+  WinPlan p;
+  p.W = (255 + c - 1) / c;
+  uint32_t off = 0;
+  for (int j = 0; j < p.W; j++) {
+    p.bits[j] = (uint8_t)c;
+    p.off[j] = off;
+    off += 1u << (c - 1);
+  }
+  p.per_base = off;
+  return p;
+}
+// Table budgets against free HBM: a reserve for the prover's working set (two pipeline sets of
+// value file + a, b, c, NTT scratch, MSM partials: ~25 GB at B = 1024, Arbo-160), then 64 % of the
+// rest for the G1 bases of a key and 34 % for its G2 bases.  Arbo-160 on a 288 GiB MI355X:
+// 25 windows for G1 (5 x 11 + 20 x 10 bits, 170 GB), 23 for G2 (2 x 12 + 21 x 11 bits, 89 GB).
+double table_budget(int group) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  const double budget = (group == 1 ? 0.60 : 0.30) * (double)free_b;
+  const double usable = (double)free_b - 28e9;
+  return (group == 1 ? 0.64 : 0.34) * (usable > 0 ? usable : 0.0);
+}
+WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes) {
   const double entry = group == 1 ? 64.0 : 128.0;
-  int best = 4;
-  for (int c = 4; c <= 12; c++) {
-    const int W = (255 + c - 1) / c;
-    const double bytes = (double)n * W * (double)(1u << (c - 1)) * entry;
-    if (bytes <= budget) best = c;
+  for (int W = 16; W <= 64; W++) {
+    WinPlan p = plan_with_windows(W);
+    if ((double)n_total * p.per_base * entry <= budget_bytes) return p;
   }
-  return best;
+  return plan_with_windows(64);
 }
 
 template <class F>
-static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c, int W,
+static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
-  const uint32_t D = 1u << (c - 1);
+  const uint32_t D = 1u << (plan.bits[0] - 1);
   // slab of threads sized so the inversion scratch stays under ~2 GB
   size_t per_thread = (size_t)3 * D * sizeof(F);
   size_t T = (size_t)2e9 / per_thread;
@@ -209,7 +244,7 @@ static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c
   if (rc) return rc;
   for (size_t i0 = 0; i0 < n; i0 += T) {
     hipLaunchKernelGGL((msm_build_table<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
-                       bases_dev, (uint32_t)i0, (uint32_t)n, c, W, table, (F*)scratch,
+                       bases_dev, (uint32_t)i0, (uint32_t)n, plan, table, (F*)scratch,
                        (uint32_t)T, 1);
   }
   ZK_HIP(hipGetLastError());
@@ -217,39 +252,33 @@ static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, int c
   return ZKMI_OK;
 }
 
-int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, int c,
+int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, const WinPlan& plan,
                     zkmi_msm_bases** out) {
   if (group != 1 && group != 2) {
     ctx->err = "group must be 1 (G1) or 2 (G2)";
     return ZKMI_ERR_ARG;
   }
-  if (c == 0) c = default_window(n, group);
-  if (c < 2 || c > 16) {
-    ctx->err = "window_bits must be in [2,16]";
-    return ZKMI_ERR_ARG;
-  }
   auto* b = new zkmi_msm_bases();
   b->group = group;
   b->n = n;
-  b->c = c;
-  b->n_windows = (255 + c - 1) / c;
+  b->plan = plan;
   const size_t entry = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
-  b->table_bytes = n * (size_t)b->n_windows * ((size_t)1 << (c - 1)) * entry;
+  b->table_bytes = n * (size_t)plan.per_base * entry;
   if (n == 0) {
     *out = b;
     return ZKMI_OK;
   }
   hipError_t e = hipMalloc(&b->table, b->table_bytes);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     ctx->err = "hipMalloc of MSM window table failed (" + std::to_string(b->table_bytes) +
                " bytes): " + hipGetErrorString(e);
     delete b;
     return ZKMI_ERR_OOM;
   }
-  int rc = group == 1 ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, c, b->n_windows,
-                                       (G1Affine*)b->table)
-                      : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, c, b->n_windows,
-                                        (G2Affine*)b->table);
+  int rc = group == 1
+               ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table)
+               : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan, (G2Affine*)b->table);
   if (rc) {
     hipFree(b->table);
     delete b;
@@ -291,11 +320,11 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   if (n == 1)
     hipLaunchKernelGGL((msm_accumulate<F, true>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial);
   else
     hipLaunchKernelGGL((msm_accumulate<F, false>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->c, bases->n_windows, (XYZZ<F>*)partial);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial);
   if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
   // two-level sum of the per-chunk partials (sqrt(chunks) groups) keeps the tail parallel
   uint32_t group = 1;

@@ -72,11 +72,21 @@ struct zkmi_ctx {
   bool msm_ev_on = false;
 };
 
+// Window plan of a fixed-base table: W windows whose sizes sum to exactly 255 bits (scalars are
+// below 2^254, so the top window also absorbs the last signed-digit carry).  `rem` windows of
+// (c0 + 1) bits come first, then W - rem windows of c0 bits.  Window j of base i holds the
+// 2^(bits_j - 1) positive multiples d * 2^(shift_j) * P_i at entry offset i*per_base + off_j.
+struct WinPlan {
+  int W = 0;
+  uint32_t per_base = 0;   // table entries per base
+  uint8_t bits[64] = {};
+  uint32_t off[64] = {};
+};
+
 struct zkmi_msm_bases {
   int group = 1;        // 1 = G1, 2 = G2
   size_t n = 0;         // number of bases
-  int c = 0;            // window bits
-  int n_windows = 0;
+  WinPlan plan;
   void* table = nullptr;  // affine entries [(i * W + j) << (c-1) | (d-1)]
   size_t table_bytes = 0;
 };
@@ -153,8 +163,12 @@ int compute_h_bi(zkmi_ctx* ctx, const NttPlan* plan, Fr* a, Fr* b, Fr* c, Fr* t0
                  size_t n_valid, Fr** h_out);
 
 // msm.hip
-int default_window(size_t n_bases_total, int group);
-int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, int c,
+// smallest number of windows whose table for n_total bases fits `budget_bytes`
+WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes);
+WinPlan plan_uniform(int c);
+WinPlan plan_with_windows(int W);
+double table_budget(int group);
+int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, const WinPlan& plan,
                     zkmi_msm_bases** out);
 // scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)
 // maps base i to its scalar row.  out_xyzz: Bp accumulators.

@@ -53,6 +53,7 @@ SYMBOLS = [
     ("zkmi_fixed_base_mul", _I, [_P, _I, _P, _P, _SZ, _P]),
     ("zkmi_pk_load", _I, [_P, C.POINTER(PkDesc), C.POINTER(_P)]),
     ("zkmi_pk_free", None, [_P, _P]),
+    ("zkmi_pk_info", _I, [_P, C.POINTER(C.c_uint64)]),
     ("zkmi_cs_load", _I, [_P, C.POINTER(CsDesc), C.POINTER(_P)]),
     ("zkmi_cs_free", None, [_P, _P]),
     ("zkmi_solve_batch", _I, [_P, _P, _P, _SZ, _P, _P, _P]),
@@ -180,6 +181,12 @@ class Context:
         h = C.c_void_p()
         self._check(self.lib.zkmi_pk_load(self.h, C.byref(desc), C.byref(h)), "zkmi_pk_load")
         return h
+
+    def pk_info(self, h):
+        arr = (C.c_uint64 * 6)()
+        self._check(self.lib.zkmi_pk_info(h, arr), "zkmi_pk_info")
+        return dict(zip(("g1_windows", "g1_entries_per_base", "g2_windows", "g2_entries_per_base",
+                         "g1_table_bytes", "g2_table_bytes"), [int(x) for x in arr]))
 
     def pk_free(self, h):
         self.lib.zkmi_pk_free(self.h, h)

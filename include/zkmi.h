@@ -111,6 +111,10 @@ typedef struct {
  * afterwards.  One-off per circuit (gnark's icicle backend does the same lazily). */
 int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* desc, zkmi_pk** out);
 void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk);
+/* Window plan chosen for the key: info[0] = windows per G1 scalar, [1] = table entries per G1
+ * base, [2] = windows per G2 scalar, [3] = table entries per G2 base, [4] = G1 table bytes (all
+ * four MSMs), [5] = G2 table bytes. */
+int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 6 */);
 
 /* -- constraint system (witness program) ----------------------------------------------------- */
 /* What cs.R1CS.Solve needs, in the straight-line form produced by
