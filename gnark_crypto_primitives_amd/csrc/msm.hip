@@ -311,7 +311,12 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   // partials + room for the intermediate level of the reduction
   int rc = ensure_scratch(ctx, 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
-  const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
+  static const unsigned bx_cfg = [] {
+    const char* e = getenv("ZKMI_MSM_BLOCK");
+    const long v = e ? atol(e) : 256;
+    return (unsigned)(v == 64 || v == 128 ? v : 256);
+  }();
+  const unsigned bx = (Bp % bx_cfg == 0) ? bx_cfg : 64;
   const int ev = (ctx->msm_ev_on && n > 1 && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
   if (ev >= 0) {
     ctx->msm_ev_group[ev] = bases->group;
