@@ -209,7 +209,7 @@ def main():
                        "parallelism": f"batch-split x{world}, no collective"},
             "pipelined": not args.no_pipeline,
             "stage_ms": {"solve": stage[0], "quotient_7ntt": stage[1], "msm_g1": stage[2],
-                         "msm_g2": stage[3], "assemble": stage[4], "quotient_to_assemble": stage[5],
+                         "msm_g2": stage[3], "assemble_overlapped": stage[4], "main_stream_span": stage[5],
                          "msm_g1_kernel_only": stage[6], "msm_g2_kernel_only": stage[7]},
             "unsatisfied": n_bad,
             "roofline": roofline,

@@ -217,15 +217,23 @@ int zkmi_init(int device, zkmi_ctx** out) {
     delete ctx;
     return ZKMI_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) {
+    hipStreamDestroy(ctx->stream2);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ZKMI_ERR_HIP;
+  }
   for (auto& st : ctx->sets) {
     hipEventCreate(&st.ev0);
     hipEventCreate(&st.ev1);
+    for (auto& e : st.evq) hipEventCreate(&e);
+    for (auto& e : st.eva) hipEventCreate(&e);
+    for (auto& p : st.msm_ev) {
+      hipEventCreate(&p[0]);
+      hipEventCreate(&p[1]);
+    }
   }
   for (auto& e : ctx->ev) hipEventCreate(&e);
-  for (auto& p : ctx->msm_ev) {
-    hipEventCreate(&p[0]);
-    hipEventCreate(&p[1]);
-  }
   ctx->plans.reserve(32);
   *out = ctx;
   return ZKMI_OK;
@@ -236,11 +244,21 @@ void zkmi_destroy(zkmi_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
+  hipStreamSynchronize(ctx->stream3);
   for (auto& st : ctx->sets) {
     if (st.ev0) hipEventDestroy(st.ev0);
     if (st.ev1) hipEventDestroy(st.ev1);
+    for (auto& e : st.evq)
+      if (e) hipEventDestroy(e);
+    for (auto& e : st.eva)
+      if (e) hipEventDestroy(e);
+    for (auto& p : st.msm_ev) {
+      if (p[0]) hipEventDestroy(p[0]);
+      if (p[1]) hipEventDestroy(p[1]);
+    }
   }
   hipStreamDestroy(ctx->stream2);
+  hipStreamDestroy(ctx->stream3);
   for (auto& p : ctx->plans) {
     hipFree(p.tw_fwd);
     hipFree(p.tw_inv);
@@ -254,10 +272,6 @@ void zkmi_destroy(zkmi_ctx* ctx) {
     if (s.p) hipFree(s.p);
   for (auto& e : ctx->ev)
     if (e) hipEventDestroy(e);
-  for (auto& p : ctx->msm_ev) {
-    if (p[0]) hipEventDestroy(p[0]);
-    if (p[1]) hipEventDestroy(p[1]);
-  }
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -772,9 +786,13 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
         (rc = ensure_scratch(ctx, ob + 1, n * Bp * 32, &dummy)) ||
         (rc = ensure_scratch(ctx, ob + 2, n * Bp * 32, &dummy)) ||
         (rc = ensure_scratch(ctx, ob + 3, n * Bp * 32, &dummy)) ||
-        (rc = ensure_scratch(ctx, ob + 5, Bp * (96 + 4) + batch * (n_in * 32 + 64), &dummy)))
+        (rc = ensure_scratch(ctx, ob + 5, Bp * (96 + 4) + batch * (n_in * 32 + 64), &dummy)) ||
+        (rc = ensure_scratch(ctx, si == 0 ? 15 : 14, Bp * (7 * 128 + 2 * 256 + 256), &dummy)))
       return rc;
   }
+  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15, Bp * (7 * 128 + 2 * 256 + 256), &S.sums)))
+    return rc;
+  S.heavy_enqueued = false;
   if ((rc = ensure_scratch(ctx, base + 0, (size_t)cs->n_slots * Bp * 32, &S.slots)) ||
       (rc = ensure_scratch(ctx, base + 1, n * Bp * 32, &S.a)) ||
       (rc = ensure_scratch(ctx, base + 2, n * Bp * 32, &S.b)) ||
@@ -817,93 +835,124 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
   return ZKMI_OK;
 }
 
+struct SumsView {
+  G1XYZZ *sA, *sB1, *sK, *sZ, *tR, *tS, *tNRS;
+  G2XYZZ *sB2, *tS2;
+  ProofOut* proofs;
+  SumsView(void* base, size_t Bp) {
+    char* m = (char*)base;
+    sA = (G1XYZZ*)m;   m += Bp * 128;
+    sB1 = (G1XYZZ*)m;  m += Bp * 128;
+    sK = (G1XYZZ*)m;   m += Bp * 128;
+    sZ = (G1XYZZ*)m;   m += Bp * 128;
+    tR = (G1XYZZ*)m;   m += Bp * 128;
+    tS = (G1XYZZ*)m;   m += Bp * 128;
+    tNRS = (G1XYZZ*)m; m += Bp * 128;
+    sB2 = (G2XYZZ*)m;  m += Bp * 256;
+    tS2 = (G2XYZZ*)m;  m += Bp * 256;
+    proofs = (ProofOut*)m;
+  }
+};
+
+// The ALU-heavy part of stage 2 (quotient, five MSMs, the one-base delta MSMs) of set `si`, on the
+// main stream.  Everything it touches besides the set's own buffers (NTT scratch, MSM partials) is
+// only used on the main stream, so consecutive batches simply queue up behind each other.
+static int enqueue_heavy(zkmi_ctx* ctx, int si) {
+  zkmi_ctx::ProveSet& S = ctx->sets[si];
+  const zkmi_pk* pk = S.pk;
+  const zkmi_cs* cs = S.cs;
+  const size_t Bp = S.Bp, n = (size_t)1 << pk->log_n;
+  NttPlan* plan;
+  int rc = get_plan(ctx, (int)pk->log_n, &plan);
+  if (rc) return rc;
+  void* t0;
+  if ((rc = ensure_scratch(ctx, 4, n * Bp * 32, &t0))) return rc;
+  SumsView v(S.sums, Bp);
+  Fr* rs_bi = (Fr*)S.rs;
+  Fr* slots = (Fr*)S.slots;
+  ZK_HIP(hipStreamWaitEvent(ctx->stream, S.ev1, 0));
+  hipEventRecord(S.evq[0], ctx->stream);
+  Fr* h;
+  if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, cs->n_constraints,
+                         &h)))
+    return rc;
+  hipEventRecord(S.evq[1], ctx->stream);
+  S.msm_ev_used = 0;
+  ctx->msm_ev_set = si;
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK)) ||
+      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ))) {
+    ctx->msm_ev_set = -1;
+    return rc;
+  }
+  hipEventRecord(S.evq[2], ctx->stream);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2);
+  ctx->msm_ev_set = -1;
+  if (rc) return rc;
+  hipEventRecord(S.evq[3], ctx->stream);
+  hipLaunchKernelGGL(rs_prep_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, rs_bi, Bp);
+  if ((rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 0, Bp, v.tR)) ||
+      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 1, Bp, v.tS)) ||
+      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, v.tNRS)) ||
+      (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, v.tS2)))
+    return rc;
+  hipEventRecord(S.evq[4], ctx->stream);
+  S.heavy_enqueued = true;
+  return ZKMI_OK;
+}
+
 // Stage 2: quotient, MSMs, assembly of the oldest submitted batch; blocks until its proofs are
-// in proofs_out / status_out.
+// in proofs_out / status_out.  The latency-bound assembly (16 wavefronts) runs on a third stream
+// and, when another batch is already submitted, that batch's quotient + MSM kernels are queued on
+// the main stream BEFORE waiting, so the assembly of batch k overlaps the quotient of batch k+1.
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
   ZK_HIP(hipSetDevice(ctx->device));
-  zkmi_ctx::ProveSet& S = ctx->sets[ctx->next_collect];
+  const int si = ctx->next_collect;
+  zkmi_ctx::ProveSet& S = ctx->sets[si];
   if (!S.pending) {
     ctx->err = "prove: nothing submitted";
     return ZKMI_ERR_ARG;
   }
   const zkmi_pk* pk = S.pk;
-  const zkmi_cs* cs = S.cs;
   const size_t batch = S.batch, Bp = S.Bp;
-  const size_t n = (size_t)1 << pk->log_n;
-  NttPlan* plan;
-  int rc = get_plan(ctx, (int)pk->log_n, &plan);
-  if (rc) return rc;
-  Staged sp(ctx), sst(ctx);
-  if ((rc = sp.out(proofs_out, batch * 256)) || (rc = sst.out(status_out, batch * 4))) return rc;
-  void *t0, *misc;
-  const size_t misc_bytes = Bp * (7 * 128 + 2 * 256 + 256);
-  if ((rc = ensure_scratch(ctx, 4, n * Bp * 32, &t0)) ||
-      (rc = ensure_scratch(ctx, 14, misc_bytes, &misc)))
-    return rc;
-  char* m = (char*)misc;
-  Fr* rs_bi = (Fr*)S.rs;
-  G1XYZZ* sA = (G1XYZZ*)m;                  m += Bp * 128;
-  G1XYZZ* sB1 = (G1XYZZ*)m;                 m += Bp * 128;
-  G1XYZZ* sK = (G1XYZZ*)m;                  m += Bp * 128;
-  G1XYZZ* sZ = (G1XYZZ*)m;                  m += Bp * 128;
-  G1XYZZ* tR = (G1XYZZ*)m;                  m += Bp * 128;
-  G1XYZZ* tS = (G1XYZZ*)m;                  m += Bp * 128;
-  G1XYZZ* tNRS = (G1XYZZ*)m;                m += Bp * 128;
-  G2XYZZ* sB2 = (G2XYZZ*)m;                 m += Bp * 256;
-  G2XYZZ* tS2 = (G2XYZZ*)m;                 m += Bp * 256;
-  ProofOut* proofs = (ProofOut*)m;
-  Fr* slots = (Fr*)S.slots;
-
-  ZK_HIP(hipStreamWaitEvent(ctx->stream, S.ev1, 0));
-  hipEventRecord(ctx->ev[1], ctx->stream);
-  Fr* h;
-  if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, cs->n_constraints,
-                         &h)))
-    return rc;
-  hipEventRecord(ctx->ev[2], ctx->stream);
-  ctx->msm_ev_used = 0;
-  ctx->msm_ev_on = true;
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, sA)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, sB1)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, sK)) ||
-      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, sZ)))
-    return rc;
-  hipEventRecord(ctx->ev[3], ctx->stream);
-  if ((rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, sB2))) return rc;
-  hipEventRecord(ctx->ev[4], ctx->stream);
-  ctx->msm_ev_on = false;
-  hipLaunchKernelGGL(rs_prep_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, rs_bi, Bp);
-  if ((rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 0, Bp, tR)) ||
-      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 1, Bp, tS)) ||
-      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, tNRS)) ||
-      (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, tS2)))
-    return rc;
+  int rc;
+  if (!S.heavy_enqueued && (rc = enqueue_heavy(ctx, si))) return rc;
+  SumsView v(S.sums, Bp);
+  hipStream_t q3 = ctx->stream3;
+  ZK_HIP(hipStreamWaitEvent(q3, S.evq[4], 0));
+  hipEventRecord(S.eva[0], q3);
   PkConsts pc{pk->alpha, pk->beta1, pk->beta2};
-  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, sA, sB1,
-                     sK, sZ, tR, tS, tNRS, rs_bi, Bp, pc, proofs);
-  hipLaunchKernelGGL(assemble_g2_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, sB2,
-                     tS2, Bp, pk->beta2, proofs);
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, q3, v.sA, v.sB1, v.sK,
+                     v.sZ, v.tR, v.tS, v.tNRS, (const Fr*)S.rs, Bp, pc, v.proofs);
+  hipLaunchKernelGGL(assemble_g2_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, q3, v.sB2, v.tS2,
+                     Bp, pk->beta2, v.proofs);
   ZK_HIP(hipGetLastError());
-  ZK_HIP(hipMemcpyAsync(sp.dev, proofs, batch * 256, hipMemcpyDeviceToDevice, ctx->stream));
-  ZK_HIP(hipMemcpyAsync(sst.dev, S.st, batch * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  hipEventRecord(ctx->ev[5], ctx->stream);
-  if ((rc = sp.finish()) || (rc = sst.finish())) return rc;
-  ZK_HIP(hipStreamSynchronize(ctx->stream));
+  ZK_HIP(hipMemcpyAsync(proofs_out, v.proofs, batch * 256, hipMemcpyDefault, q3));
+  ZK_HIP(hipMemcpyAsync(status_out, S.st, batch * 4, hipMemcpyDefault, q3));
+  hipEventRecord(S.eva[1], q3);
+  // look ahead: queue the next batch's heavy kernels before blocking on this batch's assembly
+  zkmi_ctx::ProveSet& N = ctx->sets[si ^ 1];
+  if (N.pending && !N.heavy_enqueued && (rc = enqueue_heavy(ctx, si ^ 1))) return rc;
+  ZK_HIP(hipStreamSynchronize(q3));
   S.pending = false;
+  S.heavy_enqueued = false;
   ctx->next_collect ^= 1;
   float ms = 0;
   hipEventElapsedTime(&ms, S.ev0, S.ev1);
   ctx->timings[0] = ms;
-  for (int i = 1; i < 5; i++) {
-    hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
-    ctx->timings[i] = ms;
+  for (int i = 0; i < 3; i++) {
+    hipEventElapsedTime(&ms, S.evq[i], S.evq[i + 1]);
+    ctx->timings[1 + i] = ms;
   }
-  hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[5]);
-  ctx->timings[5] = ms;  // device time of stage 2 (solve overlaps the previous batch)
+  hipEventElapsedTime(&ms, S.eva[0], S.eva[1]);
+  ctx->timings[4] = ms;
+  hipEventElapsedTime(&ms, S.evq[0], S.evq[4]);
+  ctx->timings[5] = ms;  // quotient + MSMs on the main stream (solve and assembly overlap neighbours)
   ctx->timings[6] = ctx->timings[7] = 0;
-  for (int i = 0; i < ctx->msm_ev_used; i++) {
-    hipEventElapsedTime(&ms, ctx->msm_ev[i][0], ctx->msm_ev[i][1]);
-    ctx->timings[ctx->msm_ev_group[i] == 1 ? 6 : 7] += ms;
+  for (int i = 0; i < S.msm_ev_used; i++) {
+    hipEventElapsedTime(&ms, S.msm_ev[i][0], S.msm_ev[i][1]);
+    ctx->timings[S.msm_ev_group[i] == 1 ? 6 : 7] += ms;
   }
   return ZKMI_OK;
 }

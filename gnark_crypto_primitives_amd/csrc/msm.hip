@@ -317,10 +317,11 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     return (unsigned)(v == 64 || v == 128 ? v : 256);
   }();
   const unsigned bx = (Bp % bx_cfg == 0) ? bx_cfg : 64;
-  const int ev = (ctx->msm_ev_on && n > 1 && ctx->msm_ev_used < 16) ? ctx->msm_ev_used++ : -1;
+  zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
+  const int ev = (es && n > 1 && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
   if (ev >= 0) {
-    ctx->msm_ev_group[ev] = bases->group;
-    hipEventRecord(ctx->msm_ev[ev][0], ctx->stream);
+    es->msm_ev_group[ev] = bases->group;
+    hipEventRecord(es->msm_ev[ev][0], ctx->stream);
   }
   if (n == 1)
     hipLaunchKernelGGL((msm_accumulate<F, true>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
@@ -330,7 +331,7 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     hipLaunchKernelGGL((msm_accumulate<F, false>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
                        Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial);
-  if (ev >= 0) hipEventRecord(ctx->msm_ev[ev][1], ctx->stream);
+  if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
   // two-level sum of the per-chunk partials (sqrt(chunks) groups) keeps the tail parallel
   uint32_t group = 1;
   while ((size_t)group * group < chunks) group++;

@@ -55,9 +55,17 @@ struct zkmi_ctx {
   zk::DevBuf scratch[16];
   // software pipeline over batches: the latency-bound witness solve of batch k+1 runs on
   // `stream2` (16 wavefronts at batch 1024) underneath the NTT/MSM kernels of batch k.
-  hipStream_t stream2 = nullptr;
+  // `stream3` runs the 16-wavefront assembly of batch k underneath the quotient kernels of batch k+1.
+  hipStream_t stream2 = nullptr, stream3 = nullptr;
   struct ProveSet {
     bool pending = false;
+    bool heavy_enqueued = false;   // quotient + MSMs of this batch are already on the main stream
+    void* sums = nullptr;          // MSM results, delta multiples, assembled proofs
+    hipEvent_t evq[5] = {};        // main stream: start, after NTTs, after G1 MSMs, after G2, done
+    hipEvent_t eva[2] = {};        // stream3: assembly start / end
+    hipEvent_t msm_ev[8][2] = {};  // around every proving-key msm_accumulate launch
+    int msm_ev_group[8] = {};
+    int msm_ev_used = 0;
     size_t batch = 0, Bp = 0;
     const zkmi_pk* pk = nullptr;
     const zkmi_cs* cs = nullptr;
@@ -65,11 +73,8 @@ struct zkmi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // solve start / end on stream2
   } sets[2];
   int next_submit = 0, next_collect = 0;
-  // HIP event pairs bracketing every msm_accumulate launch of the current prove call
-  hipEvent_t msm_ev[16][2] = {};
-  int msm_ev_group[16] = {};
-  int msm_ev_used = 0;
-  bool msm_ev_on = false;
+  // set whose proving-key MSM launches are currently being bracketed with HIP events (or null)
+  int msm_ev_set = -1;
 };
 
 // Window plan of a fixed-base table: W windows whose sizes sum to exactly 255 bits (scalars are

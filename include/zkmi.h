@@ -148,7 +148,9 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
 /* The same prove split in two so that consecutive batches overlap: `submit` stages the inputs and
  * runs the witness solve on a second HIP stream, `collect` runs quotient + MSMs + assembly of the
  * OLDEST submitted batch and blocks until its proofs are written.  At most two batches may be in
- * flight; submit(k+1) before collect(k) hides the latency-bound solve under batch k's MSMs.
+ * flight; submit(k+1) before collect(k) hides the latency-bound solve of batch k+1 under batch
+ * k's MSMs, and collect(k) queues batch k+1's quotient and MSM kernels before it waits, so batch
+ * k's (equally latency-bound) assembly runs underneath them on a third stream.
  * Device-pointer inputs / rs must stay valid until the matching collect.  While a batch is in
  * flight the other entry points of the same context return ZKMI_ERR_ARG. */
 int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
@@ -157,9 +159,10 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
 
 /* Per-stage device time of the last zkmi_prove_collect / zkmi_prove_batch in milliseconds, from
  * HIP events on the library's streams: [0] solve (stage 1, second stream), [1] quotient (NTTs +
- * pointwise), [2] G1 MSMs, [3] G2 MSM, [4] assembly, [5] stage 2 total = [1]..[4] (the solve
- * overlaps the previous batch), [6] sum over the four G1 msm_accumulate launches alone (one event
- * pair around each launch), [7] the G2 msm_accumulate launch alone. */
+ * pointwise), [2] G1 MSMs, [3] G2 MSM, [4] assembly (third stream; overlaps the next batch's
+ * quotient when one is submitted), [5] main-stream span = [1] + [2] + [3] + delta multiples,
+ * [6] sum over the four G1 msm_accumulate launches alone (one event pair around each launch),
+ * [7] the G2 msm_accumulate launch alone. */
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out /* 8 doubles */);
 
 #ifdef __cplusplus
