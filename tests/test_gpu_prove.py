@@ -239,3 +239,22 @@ def test_groth16_regression_fixture_gpu(zk_ctx):
         prover.close()
         assert not status.any()
         assert [p.tobytes().hex() for p in proofs] == fx["proofs_hex"]
+
+
+def test_every_opcode_on_gpu(zk_ctx):
+    """The circuit of tests/test_frontend.py::Mixed touches every witness-program opcode
+    (ToBinary, IsZero, DivUnchecked, Inverse, Select, Lookup2, Xor, Or, ...): GPU solve and prove
+    against the oracle, including unsatisfiable inputs (bad output, overflowing ToBinary, x/0)."""
+    from tests.test_frontend import Mixed, _mixed_expected
+    cc = compile_circuit(Mixed())
+    rng = random.Random(77)
+    asg = []
+    for i in range(40):
+        x = rng.randrange(1 << 16)
+        y = x if i % 5 == 0 else rng.randrange(H.R)
+        asg.append({"X": x, "Y": y, "Z": _mixed_expected(x, y)})
+    asg[3]["Z"] = (asg[3]["Z"] + 1) % H.R
+    asg[9] = {"X": 1 << 20, "Y": 7, "Z": 0}
+    asg[11] = {"X": 5, "Y": H.R - 2, "Z": 0}
+    status = _prove_and_check(zk_ctx, cc, asg, 12)
+    assert list(status != 0) == [i in (3, 9, 11) for i in range(40)]
