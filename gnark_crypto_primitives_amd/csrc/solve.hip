@@ -14,11 +14,13 @@
 //   * OP_ABC copies the three operand values of constraint k into the quotient inputs a, b, c,
 //     and for assertion-type constraints checks a*b == c (per-proof status).
 // Opcodes: frontend/api.py.
+#include <cstdlib>
+
 #include "zkmi_internal.h"
 
 namespace zk {
 
-__global__ __launch_bounds__(64) void solve_kernel(const uint4* __restrict__ prog,
+__global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ prog,
                                                    const Fr* __restrict__ consts, Fr* slots,
                                                    Fr* __restrict__ a, Fr* __restrict__ b,
                                                    Fr* __restrict__ c, int32_t* __restrict__ status,
@@ -129,7 +131,15 @@ __global__ void fill_one_row(Fr* row, size_t Bp) {
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
              size_t Bp) {
   hipLaunchKernelGGL(fill_one_row, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, slots, Bp);
-  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
+  // ZKMI_SOLVE_BLOCK: lanes per block (64 spreads the 16 waves of a 1024-proof batch over 16 CUs,
+  // 256 packs them on 4)
+  static const unsigned sb = [] {
+    const char* e = getenv("ZKMI_SOLVE_BLOCK");
+    const long v = e ? atol(e) : 64;
+    return (unsigned)(v == 128 || v == 256 ? v : 64);
+  }();
+  const unsigned bs = (Bp % sb == 0) ? sb : 64;
+  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)(Bp / bs)), dim3(bs), 0, ctx->stream,
                      (const uint4*)cs->program, cs->consts, slots, a, b, c, status, Bp, cs->n_ops);
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
