@@ -695,6 +695,12 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
       zkmi_cs_free(ctx, cs);
       return ZKMI_ERR_HIP;
     }
+    // the solver works in the 2^261 domain (solve.hip)
+    if ((rc = array_to_f_domain(ctx, cs->consts, d->n_consts)) ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      zkmi_cs_free(ctx, cs);
+      return rc ? rc : ZKMI_ERR_HIP;
+    }
   }
   *out = cs;
   return ZKMI_OK;
@@ -704,7 +710,9 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
 static int stage_inputs(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs_dev, size_t batch,
                         size_t Bp, Fr* slots) {
   const size_t n_in = cs->n_public - 1 + cs->n_secret;
-  return transpose_in(ctx, inputs_dev, slots + Bp, n_in, batch, Bp, 32);
+  int rc = transpose_in(ctx, inputs_dev, slots + Bp, n_in, batch, Bp, 32);
+  if (rc) return rc;
+  return rows_to_f_domain(ctx, slots + Bp, n_in, Bp);
 }
 
 int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_t batch,
@@ -733,8 +741,15 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
     return rc;
   if ((rc = stage_inputs(ctx, cs, si.dev, batch, Bp, (Fr*)slots))) return rc;
   if ((rc = solve_bi(ctx, cs, (Fr*)slots, (Fr*)a, (Fr*)b, (Fr*)c, (int32_t*)st, Bp))) return rc;
-  if (wires_out && (rc = transpose_out(ctx, slots, sw.dev, cs->n_wires, batch, Bp, 32))) return rc;
+  // back to gnark's image for the caller
+  if (wires_out && ((rc = rows_to_std_domain(ctx, (Fr*)slots, cs->n_wires, Bp)) ||
+                    (rc = transpose_out(ctx, slots, sw.dev, cs->n_wires, batch, Bp, 32))))
+    return rc;
   if (abc_out) {
+    if ((rc = rows_to_std_domain(ctx, (Fr*)a, cs->n_constraints, Bp)) ||
+        (rc = rows_to_std_domain(ctx, (Fr*)b, cs->n_constraints, Bp)) ||
+        (rc = rows_to_std_domain(ctx, (Fr*)c, cs->n_constraints, Bp)))
+      return rc;
     const size_t stride = batch * (size_t)cs->n_constraints * 32;
     if ((rc = transpose_out(ctx, a, sabc.dev, cs->n_constraints, batch, Bp, 32)) ||
         (rc = transpose_out(ctx, b, (char*)sabc.dev + stride, cs->n_constraints, batch, Bp, 32)) ||
@@ -820,6 +835,7 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
   ctx->stream = q;  // the helpers launch on ctx->stream
   hipEventRecord(S.ev0, q);
   rc = transpose_in(ctx, in_dev, (Fr*)S.slots + Bp, n_in, batch, Bp, 32);
+  if (!rc) rc = rows_to_f_domain(ctx, (Fr*)S.slots + Bp, n_in, Bp);
   if (!rc) rc = transpose_in(ctx, rs_dev, S.rs, 2, batch, Bp, 32);
   if (!rc)
     rc = solve_bi(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp);
@@ -874,20 +890,20 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   hipEventRecord(S.evq[0], ctx->stream);
   Fr* h;
   if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, cs->n_constraints,
-                         &h)))
+                         &h, true)))
     return rc;
   hipEventRecord(S.evq[1], ctx->stream);
   S.msm_ev_used = 0;
   ctx->msm_ev_set = si;
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK)) ||
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true)) ||
       (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ))) {
     ctx->msm_ev_set = -1;
     return rc;
   }
   hipEventRecord(S.evq[2], ctx->stream);
-  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true);
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
                                                       const Fr* __restrict__ scalars,
                                                       const uint32_t* __restrict__ row_idx,
                                                       size_t Bp, uint32_t n, uint32_t per_chunk,
-                                                      WinPlan plan, XYZZ<F>* __restrict__ partial) {
+                                                      WinPlan plan, XYZZ<F>* __restrict__ partial,
+                                                      Fr kmul) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t chunk = blockIdx.y;
   const uint32_t i0 = chunk * per_chunk;
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restric
   typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t i = i0; i < i1; i++) {
     const uint32_t row = row_idx ? row_idx[i] : i;
-    Fr s = from_mont(bi_ld(scalars, row, b, Bp));
+    // Montgomery image -> integer: product by the plain constant 1 (gnark's x*2^256) or by
+    // 2^-5 (the solver's x*2^261)
+    Fr s = mul(bi_ld(scalars, row, b, Bp), kmul);
     if (s.is_zero()) continue;
     const Affine<F>* trow = table + (size_t)i * plan.per_base;
     uint32_t carry = 0;
@@ -290,7 +293,14 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 
 template <class F>
 static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
-                    const uint32_t* row_idx, size_t Bp, XYZZ<F>* out) {
+                    const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f) {
+  Fr kmul = Fr::zero();
+  kmul.v[0] = 1;  // plain 1: from_mont
+  if (scalars_f) {  // plain 2^-5 mod r
+    Fr t = Fr::zero();
+    t.v[0] = 32;
+    kmul = from_mont(inverse(to_mont(t)));
+  }
   const size_t n = bases->n;
   // 8 x as many chunks as it takes to put 4 waves on every SIMD: all blocks of the coarse grid
   // run for the whole kernel, so a few occupied wave slots (the overlapped solve of the next
@@ -326,11 +336,11 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   if (n == 1)
     hipLaunchKernelGGL((msm_accumulate<F, true>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul);
   else
     hipLaunchKernelGGL((msm_accumulate<F, false>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul);
   if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
   // two-level sum of the per-chunk partials (sqrt(chunks) groups) keeps the tail parallel
   uint32_t group = 1;
@@ -360,7 +370,7 @@ __global__ void fill_inf_g2(G2XYZZ* out, size_t n) {
 }
 
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz) {
+            size_t Bp, void* out_xyzz, bool scalars_f) {
   if (bases->n == 0) {
     if (bases->group == 1)
       hipLaunchKernelGGL(fill_inf_g1, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
@@ -371,8 +381,9 @@ int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
   }
-  if (bases->group == 1) return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz);
-  return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz);
+  if (bases->group == 1)
+    return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz, scalars_f);
+  return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz, scalars_f);
 }
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n) {

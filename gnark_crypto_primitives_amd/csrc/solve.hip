@@ -14,11 +14,55 @@
 //   * OP_ABC copies the three operand values of constraint k into the quotient inputs a, b, c,
 //     and for assertion-type constraints checks a*b == c (per-proof status).
 // Opcodes: frontend/api.py.
+//
+// Value domain.  88 % of the solver's issue slots are field products (96 872 per proof at
+// Arbo-160).  The value file therefore holds x * 2^261 mod r (canonical, packed 8 x u32: the "F
+// domain" of ff29.h) instead of gnark's x * 2^256: additions and subtractions are the same carry
+// chains either way, products run on the 9 x 29-bit representation (257 instructions instead of
+// ~540).  Inputs and constants are converted when they are staged (one product by 2^5 each); the
+// consumers convert for free: the MSMs fold 2^-5 into their Montgomery-to-integer product, the
+// quotient's first pass skips its own 2^266 conversion.
 #include <cstdlib>
 
 #include "zkmi_internal.h"
+#include "ff29.h"
 
 namespace zk {
+
+// products / inverses / integer value of F-domain elements kept in the packed canonical image
+__device__ __forceinline__ Fr fmul(const Fr& a, const Fr& b) {
+  Fr r;
+  pack_canonical<Fr29Params>(r.v, mul(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
+  return r;
+}
+__device__ __forceinline__ Fr f_one() {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = Fr29Params::k261(i);
+  return r;
+}
+__device__ Fr finv(const Fr& a) {  // a^(r-2): 0 -> 0 (gnark-crypto Element.Inverse convention)
+  const Fr29 A = unpack29<Fr29Params>(a.v);
+  Fr29 R = Fr29::one();
+  for (int i = 7; i >= 0; i--) {
+    uint32_t e = FrParams::p(i);
+    if (i == 0) e -= 2;
+    for (int b = 31; b >= 0; b--) {
+      R = sqr(R);
+      if ((e >> b) & 1) R = mul(R, A);
+    }
+  }
+  Fr r;
+  pack_canonical<Fr29Params>(r.v, R);
+  return r;
+}
+__device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a plain integer
+  Fr29 o = Fr29::zero();
+  o.v[0] = 1;
+  Fr r;
+  pack_canonical<Fr29Params>(r.v, mul(unpack29<Fr29Params>(a.v), o));
+  return r;
+}
 
 __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ prog,
                                                    const Fr* __restrict__ consts, Fr* slots,
@@ -42,10 +86,10 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         ST(d, sub(LD(x), LD(y)));
         break;
       case OP_MUL:
-        ST(d, mul(LD(x), LD(y)));
+        ST(d, fmul(LD(x), LD(y)));
         break;
       case OP_MULC:
-        ST(d, mul(LD(x), consts[y]));
+        ST(d, fmul(LD(x), consts[y]));
         break;
       case OP_ADDC:
         ST(d, add(LD(x), consts[y]));
@@ -54,10 +98,10 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         ST(d, neg(LD(x)));
         break;
       case OP_INV:
-        ST(d, inverse(LD(x)));
+        ST(d, finv(LD(x)));
         break;
       case OP_DIV:
-        ST(d, mul(LD(x), inverse(LD(y))));
+        ST(d, fmul(LD(x), finv(LD(y))));
         break;
       case OP_SETC:
         ST(d, consts[y]);
@@ -66,8 +110,8 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         ST(d, LD(x));
         break;
       case OP_BITS: {
-        Fr v = from_mont(LD(x));
-        const Fr one = Fr::one(), zero = Fr::zero();
+        Fr v = f_plain(LD(x));
+        const Fr one = f_one(), zero = Fr::zero();
         for (uint32_t i = 0; i < y; i++) {
           const uint32_t bit = i < 256 ? (v.v[0] & 1u) : 0u;
 #pragma unroll
@@ -81,22 +125,22 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         // rows pc+1 .. pc+n are (OP_PAIR, dst, src): dst = 1/src (0 for 0) with one inversion.
         // dst rows double as the prefix-product scratch; dst and src slots are distinct wires.
         const uint32_t n = d;
-        Fr acc = Fr::one();
+        Fr acc = f_one();
         for (uint32_t k = 1; k <= n; k++) {
           const uint4 pr = prog[pc + k];
           const Fr v = LD(pr.z);
           ST(pr.y, acc);
-          if (!v.is_zero()) acc = mul(acc, v);
+          if (!v.is_zero()) acc = fmul(acc, v);
         }
-        Fr inv = inverse(acc);
+        Fr inv = finv(acc);
         for (uint32_t k = n; k >= 1; k--) {
           const uint4 pr = prog[pc + k];
           const Fr v = LD(pr.z);
           if (v.is_zero()) {
             ST(pr.y, Fr::zero());
           } else {
-            const Fr res = mul(inv, LD(pr.y));
-            inv = mul(inv, v);
+            const Fr res = fmul(inv, LD(pr.y));
+            inv = fmul(inv, v);
             ST(pr.y, res);
           }
         }
@@ -109,7 +153,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         bi_st(b, k, lane, Bp, vb);
         bi_st(c, k, lane, Bp, vc);
         if (ins.x & 0x100u) {
-          if (mul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
+          if (fmul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
         }
         k++;
         break;
@@ -125,7 +169,57 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
 
 __global__ void fill_one_row(Fr* row, size_t Bp) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < Bp) bi_st(row, 0, i, Bp, Fr::one());
+  if (i < Bp) bi_st(row, 0, i, Bp, f_one());
+}
+
+// x <- x * k / 2^256 (ff.h product by a plain-integer constant): k = 2^261 mod r moves gnark's image
+// x*2^256 into the F domain, k = 2^251 moves it back.
+__global__ __launch_bounds__(256) void scale_rows_kernel(Fr* base, size_t rows, size_t Bp, Fr k) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, total = rows * Bp;
+  for (; i < total; i += stride) {
+    const size_t row = i / Bp, l = i % Bp;
+    bi_st(base, row, l, Bp, mul(bi_ld(base, row, l, Bp), k));
+  }
+}
+__global__ __launch_bounds__(256) void scale_array_kernel(Fr* a, size_t n, Fr k) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = mul(a[i], k);
+}
+static Fr k_to_f() {
+  Fr k;
+  for (int i = 0; i < 8; i++) k.v[i] = Fr29Params::k261(i);
+  return k;
+}
+static Fr k_to_std() {  // 2^251
+  Fr k = Fr::zero();
+  k.v[7] = 1u << 27;
+  return k;
+}
+int rows_to_f_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp) {
+  if (rows == 0) return ZKMI_OK;
+  size_t g = (rows * Bp + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, base, rows,
+                     Bp, k_to_f());
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+int rows_to_std_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp) {
+  if (rows == 0) return ZKMI_OK;
+  size_t g = (rows * Bp + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, base, rows,
+                     Bp, k_to_std());
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+int array_to_f_domain(zkmi_ctx* ctx, Fr* a, size_t n) {
+  if (n == 0) return ZKMI_OK;
+  hipLaunchKernelGGL(scale_array_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, a, n, k_to_f());
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
 }
 
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,

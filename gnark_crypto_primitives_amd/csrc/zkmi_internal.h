@@ -164,8 +164,9 @@ int ntt_bi(zkmi_ctx* ctx, const NttPlan* plan, const Fr* src, Fr* dst, size_t Bp
 int pointwise_h(zkmi_ctx* ctx, const NttPlan* plan, const Fr* a, const Fr* b, const Fr* c, Fr* h,
                 size_t Bp);
 // full quotient: a,b,c batch-inner [n][Bp] (rows >= n_valid zero) -> h in `a_out`; t0,t1 scratch
+// abc_f: a, b, c are in the F domain (solver output); the result h is always in gnark's image
 int compute_h_bi(zkmi_ctx* ctx, const NttPlan* plan, Fr* a, Fr* b, Fr* c, Fr* t0, size_t Bp,
-                 size_t n_valid, Fr** h_out);
+                 size_t n_valid, Fr** h_out, bool abc_f = false);
 
 // msm.hip
 // smallest number of windows whose table for n_total bases fits `budget_bytes`
@@ -177,15 +178,21 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
                     zkmi_msm_bases** out);
 // scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)
 // maps base i to its scalar row.  out_xyzz: Bp accumulators.
+// scalars_f: the scalars are in the F domain (solver output) instead of gnark's image
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz);
+            size_t Bp, void* out_xyzz, bool scalars_f = false);
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n);
 
 // solve.hip
 // slots [n_slots][Bp] with rows 0..n_inputs pre-filled; writes every wire row, a/b/c rows
 // [0, n_constraints) and status[Bp] (0 or ZKMI_ERR_UNSATISFIED)
+// The solver's value file and its a/b/c outputs are in the F domain (x * 2^261, see solve.hip);
+// inputs must be converted with rows_to_f_domain after staging.
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
              size_t Bp);
+int rows_to_f_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp);
+int rows_to_std_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp);
+int array_to_f_domain(zkmi_ctx* ctx, Fr* a, size_t n);
 
 }  // namespace zk
