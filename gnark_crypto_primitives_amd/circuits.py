@@ -105,3 +105,17 @@ class EdDSACircuit:
         v = eddsa.NewVerifier(api, poseidon.Poseidon(api))
         v.Verify(eddsa.PublicKey(Point(*self.A)), eddsa.Signature(Point(*self.R), self.S),
                  self.Msg)
+
+
+class AddressCircuit:
+    """testAddressCircuit (ecc/secp256k1/ecdsa/address_test.go:21-33): config 5.  The public key's
+    coordinates are emulated elements, 4 x 64-bit limbs each, least significant first."""
+    Address = Public()
+    X = Secret(4)
+    Y = Secret(4)
+
+    def define(self, api):
+        from .ecc.secp256k1 import DeriveAddress, PublicKey
+        from .std.emulated import Element
+        addr = DeriveAddress(api, PublicKey(Element(self.X), Element(self.Y)))
+        api.AssertIsEqual(self.Address, addr)

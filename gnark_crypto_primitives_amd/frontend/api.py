@@ -370,13 +370,25 @@ class API:
         return res
 
     def Xor(self, a, b):
+        """gnark r1cs builder: a fresh wire res with (2a) * b == a + b - res (one constraint, and
+        the result is a single wire however long the XOR chain grows)."""
         a, b = self._v(a), self._v(b)
         self.AssertIsBoolean(a)
         self.AssertIsBoolean(b)
-        # a + b - 2ab
-        res = self.Sub(self.Add(a, b), self._mul2(self._mul2(a, 2), b))
-        if not res.is_const():
-            self._mark_boolean(res)
+        if a.is_const() or b.is_const():
+            k, x = (a, b) if a.is_const() else (b, a)
+            res = x if k.const_value() == 0 else self.Sub(1, x)
+            if not res.is_const():
+                self._mark_boolean(res)
+            return res
+        ab = self._emit(OP_MUL, a.val, b.val)
+        ab2 = self._emit(OP_ADD, ab, ab)
+        val = self._emit(OP_SUB, self._emit(OP_ADD, a.val, b.val), ab2)
+        res, w = self._internal(val)
+        two_a = Variable(_lc_scale(a.lc, 2), self._emit(OP_ADD, a.val, a.val))
+        rhs = Variable(_lc_add(_lc_add(a.lc, b.lc), res.lc, -1), ab2)
+        self._add_r1c(two_a, b, rhs, solve_wire=w)
+        self._mark_boolean(res)
         return res
 
     # ------------------------------------------------------------------ bits

@@ -10,7 +10,10 @@ C oracle (oracle/c) and the HIP path at sizes Python finishes in seconds:
     circomlib/iden3 known-answer vectors -- an algorithmically different
     path from the optimised gadget in hash/native/bn254/poseidon/poseidon.go:116-183;
   * BabyJubJub in gnark's reduced twisted-Edwards form (a = -1), pinned by K3;
-  * Groth16: R1CS evaluation at the trapdoor and the closed-form expected proof.
+  * Groth16: R1CS evaluation at the trapdoor and the closed-form expected proof;
+  * Keccak-256 (legacy padding) on a flat 25-lane state with FIPS 202's published tables, pinned
+    by hashlib.sha3_256 through the shared permutation, and secp256k1 -> Ethereum address, pinned
+    by the public vectors for private keys 1 and 2 (config 5, ecdsa.DeriveAddress).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -390,6 +393,105 @@ def smt_root_from_path(key, value, siblings):
         else:
             cur = poseidon_hash([cur, siblings[i]])
     return cur
+
+
+# ------------------------------------------------------------------ Keccak / secp256k1 address --
+# FIPS 202 tables (round constants, rho offsets in pi order, pi lane order), flat index x + 5y.
+_KECCAK_RC = [
+    0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000,
+    0x000000000000808B, 0x0000000080000001, 0x8000000080008081, 0x8000000000008009,
+    0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+    0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003,
+    0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+    0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_RHO = [1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61,
+               20, 44]
+_KECCAK_PI = [10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6,
+              1]
+_M64 = (1 << 64) - 1
+
+
+def keccak_f1600(st):
+    """In-place permutation of 25 lanes (the compact 'tiny' formulation: theta, then rho and pi as
+    one walk along the pi cycle, chi row by row, iota)."""
+    for rc in _KECCAK_RC:
+        bc = [st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20] for i in range(5)]
+        for i in range(5):
+            t = bc[(i + 4) % 5] ^ (((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63)) & _M64)
+            for j in range(0, 25, 5):
+                st[j + i] ^= t
+        t = st[1]
+        for i in range(24):
+            j = _KECCAK_PI[i]
+            nxt = st[j]
+            st[j] = ((t << _KECCAK_RHO[i]) | (t >> (64 - _KECCAK_RHO[i]))) & _M64
+            t = nxt
+        for j in range(0, 25, 5):
+            row = st[j:j + 5]
+            for i in range(5):
+                st[j + i] = row[i] ^ (~row[(i + 1) % 5] & _M64 & row[(i + 2) % 5])
+        st[0] ^= rc
+    return st
+
+
+def _sponge256(data: bytes, domain: int) -> bytes:
+    rate = 136
+    msg = bytearray(data) + bytes([domain]) + bytes(rate - 1 - len(data) % rate)
+    msg[-1] |= 0x80
+    st = [0] * 25
+    for off in range(0, len(msg), rate):
+        for k in range(rate // 8):
+            st[k] ^= int.from_bytes(msg[off + 8 * k:off + 8 * k + 8], "little")
+        keccak_f1600(st)
+    return b"".join(x.to_bytes(8, "little") for x in st[:4])
+
+
+def keccak256(data: bytes) -> bytes:
+    """Legacy (pre-NIST, Ethereum) Keccak-256: domain byte 0x01."""
+    return _sponge256(data, 0x01)
+
+
+def sha3_256(data: bytes) -> bytes:
+    """NIST SHA3-256 (domain byte 0x06): same sponge, comparable with hashlib."""
+    return _sponge256(data, 0x06)
+
+
+SECP_P = 2**256 - 2**32 - 977
+SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+SECP_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+          0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+
+
+def secp256k1_mul(k, pt=SECP_G):
+    """Jacobian double-and-add, MSB first (a = 0)."""
+    X, Y, Z = 0, 1, 0
+    for bit in bin(k % SECP_N)[2:]:
+        if Z:
+            S = 4 * X * Y * Y % SECP_P
+            M = 3 * X * X % SECP_P
+            X2 = (M * M - 2 * S) % SECP_P
+            Y, Z = (M * (S - X2) - 8 * pow(Y, 4, SECP_P)) % SECP_P, 2 * Y * Z % SECP_P
+            X = X2
+        if bit == "1":
+            if not Z:
+                X, Y, Z = pt[0], pt[1], 1
+                continue
+            zz = Z * Z % SECP_P
+            u2, s2 = pt[0] * zz % SECP_P, pt[1] * zz * Z % SECP_P
+            h, r_ = (u2 - X) % SECP_P, (s2 - Y) % SECP_P
+            assert h, "unsupported: doubling inside addition"
+            hh = h * h % SECP_P
+            hhh, v = h * hh % SECP_P, X * hh % SECP_P
+            X3 = (r_ * r_ - hhh - 2 * v) % SECP_P
+            Y, Z = (r_ * (v - X3) - Y * hhh) % SECP_P, Z * h % SECP_P
+            X = X3
+    zi = inv(Z, SECP_P)
+    return X * zi * zi % SECP_P, Y * zi * zi * zi % SECP_P
+
+
+def eth_address(pub) -> int:
+    return int.from_bytes(keccak256(pub[0].to_bytes(32, "big") + pub[1].to_bytes(32, "big"))[12:],
+                          "big")
 
 
 # ------------------------------------------------------------------ Groth16 ---------------------

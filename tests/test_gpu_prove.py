@@ -258,3 +258,23 @@ def test_every_opcode_on_gpu(zk_ctx):
     asg[11] = {"X": 5, "Y": H.R - 2, "Z": 0}
     status = _prove_and_check(zk_ctx, cc, asg, 12)
     assert list(status != 0) == [i in (3, 9, 11) for i in range(40)]
+
+
+def test_config5_secp256k1_address(zk_ctx):
+    """BASELINE config 5: ecdsa.DeriveAddress (one Keccak-f[1600] in R1CS: 151 945 constraints,
+    domain 2^18) solved and proved on the GPU; every proof bit-exact against the C oracle, the
+    address taken from the Python oracle (public vectors for keys 1 and 2)."""
+    from gnark_crypto_primitives_amd.std.emulated import limbs_of
+    from oracle import pyref
+    cc = compile_circuit(circuits.AddressCircuit())
+    assert cc.domain_log2() == 18
+    rng = random.Random(55)
+    asg = []
+    for priv in (1, 2, rng.randrange(1, pyref.SECP_N), rng.randrange(1, pyref.SECP_N)):
+        pub = pyref.secp256k1_mul(priv)
+        asg.append({"Address": pyref.eth_address(pub), "X": limbs_of(pub[0]),
+                    "Y": limbs_of(pub[1])})
+    assert asg[0]["Address"] == 0x7E5F4552091A69125D5DFCB7B8C2659029395BDF
+    asg[3] = dict(asg[3], Address=asg[2]["Address"])      # someone else's address -> unsatisfied
+    status = _prove_and_check(zk_ctx, cc, asg, 5, wbits=(5, 4))
+    assert list(status != 0) == [False, False, False, True]
