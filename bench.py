@@ -47,6 +47,12 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
+    ap.add_argument("--workload", default="arbo",
+                    help="arbo (the headline, BASELINE config 2) | poseidon | verifier | "
+                         "elgamal-add | elgamal-encrypt | address: the other configs, for "
+                         "DESIGN.md's table (distinct witnesses are cycled to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct witnesses to generate (0: one per proof)")
     ap.add_argument("--levels", type=int, default=160)
     ap.add_argument("--populated", type=int, default=10, help="non-zero siblings per path")
     ap.add_argument("--window-g1", type=int, default=0)
@@ -64,10 +70,9 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gnark_crypto_primitives_amd import backend, circuits, groth16, lib
+    from gnark_crypto_primitives_amd import backend, groth16, lib, workloads
     from gnark_crypto_primitives_amd.frontend import compile_circuit
     from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
-    from gnark_crypto_primitives_amd.tree import smt_witness
 
     rank, world, local_rank = backend.env_rank_world()
     if args.device >= 0:
@@ -85,7 +90,8 @@ def main():
 
     t0 = time.time()
     ctx = lib.Context(local_rank)
-    cc = compile_circuit(circuits.smt_inclusion_circuit(args.levels))
+    circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
+    cc = compile_circuit(circuit)
     log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops "
         f"({time.time() - t0:.1f}s)")
     pk, vk, _ = groth16.setup(cc, 2, groth16.gpu_mul(ctx))
@@ -97,9 +103,10 @@ def main():
     # synthetic witnesses, seeded per rank
     rng = random.Random(1000 + rank)
     B = args.batch
-    ws = [smt_witness.synthetic_inclusion(rng, args.levels, args.populated) for _ in range(B)]
-    inp_h = np.stack([to_mont_array(cc.assignment_vector(w)) for w in ws])
-    rs_h = np.stack([to_mont_array([rng.randrange(smt_witness.R), rng.randrange(smt_witness.R)])
+    n_distinct = min(B, args.distinct) if args.distinct > 0 else B
+    ws = [to_mont_array(cc.assignment_vector(gen(rng))) for _ in range(n_distinct)]
+    inp_h = np.stack([ws[i % n_distinct] for i in range(B)])
+    rs_h = np.stack([to_mont_array([rng.randrange(workloads.R), rng.randrange(workloads.R)])
                      for _ in range(B)])
     inp_d = torch.from_numpy(inp_h.view(np.int64)).to(dev)
     rs_d = torch.from_numpy(rs_h.view(np.int64)).to(dev)
@@ -158,7 +165,8 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if pm.get("batch") == B and pm.get("levels") == args.levels:
+            if pm.get("batch") == B and pm.get("levels") == args.levels and \
+                    args.workload == "arbo":
                 traffic = pm["msm_g1_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
@@ -194,14 +202,15 @@ def main():
                              f"OpenMP over proofs", "seconds": tc,
                    "gpu_proofs_bit_exact_vs_cpu": same}
         out = {
-            "metric": "proofs/sec, Arbo-160 Poseidon SMT-verifier circuit, Groth16/BN254",
+            "metric": "proofs/sec, Arbo-160 Poseidon SMT-verifier circuit, Groth16/BN254"
+                      if args.workload == "arbo" and args.levels == 160
+                      else f"proofs/sec, {label}, Groth16/BN254",
             "value": world * B * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)",
             "data": "synthetic",
-            "config": {"workload": f"Arbo SMT inclusion verifier, {args.levels} levels, Poseidon "
-                                   f"leaf hash, batch {B} proofs per GPU",
+            "config": {"workload": f"{label}, batch {B} proofs per GPU",
                        "constraints": cc.n_constraints, "wires": cc.n_wires,
                        "domain_log2": pk.log_n, "batch_per_gpu": B,
                        "msm_terms_per_proof": {"g1": int(sum(ns)), "g2": ns[1]},

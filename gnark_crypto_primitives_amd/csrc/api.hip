@@ -645,7 +645,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
       case OP_BITS:
         ok = a < d->n_slots && b <= 256 && (uint64_t)dst + b <= d->n_slots;
         break;
-      case OP_ABC:
+      case OP_ABC: case OP_MULABC: case OP_XORABC:
         ok = dst < d->n_slots && a < d->n_slots && b < d->n_slots;
         n_abc++;
         break;

@@ -11,6 +11,8 @@
 //   * instruction words are wave-uniform -> scalar loads; control flow never diverges;
 //   * lane = proof, so every slot access is a coalesced 2 KiB row segment;
 //   * slot i < n_wires IS wire i: the full wire matrix the MSMs read is produced in place;
+//   * OP_MULABC / OP_XORABC compute a product / a boolean XOR wire AND emit its constraint row
+//     (the two shapes almost every constraint of the gadget circuits has): one op, two loads.
 //   * OP_ABC copies the three operand values of constraint k into the quotient inputs a, b, c,
 //     and for assertion-type constraints checks a*b == c (per-proof status).
 // Opcodes: frontend/api.py.
@@ -145,6 +147,27 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
           }
         }
         pc += n;
+        break;
+      }
+      case OP_MULABC: {  // d = x * y and the row (x, y, d) in one step
+        const Fr va = LD(x), vb = LD(y);
+        const Fr vc = fmul(va, vb);
+        ST(d, vc);
+        bi_st(a, k, lane, Bp, va);
+        bi_st(b, k, lane, Bp, vb);
+        bi_st(c, k, lane, Bp, vc);
+        k++;
+        break;
+      }
+      case OP_XORABC: {  // d = x xor y = x + y - 2xy and the row (2x, y, 2xy)
+        const Fr va = LD(x), vb = LD(y);
+        const Fr ab = fmul(va, vb);
+        const Fr ab2 = add(ab, ab);
+        ST(d, sub(add(va, vb), ab2));
+        bi_st(a, k, lane, Bp, add(va, va));
+        bi_st(b, k, lane, Bp, vb);
+        bi_st(c, k, lane, Bp, ab2);
+        k++;
         break;
       }
       case OP_ABC: {

@@ -134,7 +134,7 @@ __device__ __forceinline__ void bi_st(Fr* base, size_t row, size_t b, size_t Bp,
 
 // witness-program opcodes (frontend/api.py)
 enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC,
-       OP_ABC, OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR };
+       OP_ABC, OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC };
 
 #define ZK_HIP(call)                                                         \
   do {                                                                       \

@@ -27,7 +27,7 @@ R = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 
 # witness-program opcodes (decoded by csrc/solve.hip and by CompiledCircuit.run_program)
 OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC, OP_ABC, \
-    OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR = range(15)
+    OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC = range(17)
 
 HINT_INVZERO, HINT_NBITS = 1, 2
 
@@ -158,16 +158,22 @@ class API:
     def _key(v):
         return tuple(sorted(v.lc.items()))
 
-    def _add_r1c(self, L, R_, O, solve_wire=-1, check=None):
+    def _add_r1c(self, L, R_, O, solve_wire=-1, check=None, fused=None):
         """check: the solver must verify L*R == O (assertions; divisions, where a zero divisor
-        makes the defining equation unsatisfiable)."""
+        makes the defining equation unsatisfiable).
+        fused: (opcode, dst, a, b) -- one witness-program op that both computes the new wire and
+        emits the row (OP_MULABC: dst = a*b, row (a, b, dst); OP_XORABC: dst = a xor b, row
+        (2a, b, 2ab)) instead of a value op followed by OP_ABC."""
         self._inputs_open = False
         k = len(self.constraints)
         if check is None:
             check = solve_wire < 0
         self.constraints.append((L.lc, R_.lc, O.lc, solve_wire, (L.val, R_.val, O.val), check))
         self.instr.append((0, k))
-        self._emit(OP_ABC, R_.val, O.val, dst=L.val)   # (sa, sb, sc) = (dst, a, b)
+        if fused is not None:
+            self.ops.append(fused)
+        else:
+            self._emit(OP_ABC, R_.val, O.val, dst=L.val)   # (sa, sb, sc) = (dst, a, b)
         return k
 
     def _internal(self, val):
@@ -232,9 +238,9 @@ class API:
             if kv == 1:
                 return x
             return Variable(_lc_scale(x.lc, kv), self._emit(OP_MULC, x.val, self._cid(kv)))
-        val = self._emit(OP_MUL, a.val, b.val)
+        val = self._new_val()
         res, w = self._internal(val)
-        self._add_r1c(a, b, res, solve_wire=w)
+        self._add_r1c(a, b, res, solve_wire=w, fused=(OP_MULABC, val, a.val, b.val))
         return res
 
     def Mul(self, a, b, *rest):
@@ -381,13 +387,12 @@ class API:
             if not res.is_const():
                 self._mark_boolean(res)
             return res
-        ab = self._emit(OP_MUL, a.val, b.val)
-        ab2 = self._emit(OP_ADD, ab, ab)
-        val = self._emit(OP_SUB, self._emit(OP_ADD, a.val, b.val), ab2)
+        val = self._new_val()
         res, w = self._internal(val)
-        two_a = Variable(_lc_scale(a.lc, 2), self._emit(OP_ADD, a.val, a.val))
-        rhs = Variable(_lc_add(_lc_add(a.lc, b.lc), res.lc, -1), ab2)
-        self._add_r1c(two_a, b, rhs, solve_wire=w)
+        # the row's operand values are produced by the fused op itself (no SSA ids needed)
+        two_a = Variable(_lc_scale(a.lc, 2), -1)
+        rhs = Variable(_lc_add(_lc_add(a.lc, b.lc), res.lc, -1), -1)
+        self._add_r1c(two_a, b, rhs, solve_wire=w, fused=(OP_XORABC, val, a.val, b.val))
         self._mark_boolean(res)
         return res
 

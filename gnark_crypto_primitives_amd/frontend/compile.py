@@ -14,7 +14,8 @@ import hashlib
 import numpy as np
 
 from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS,
-                  OP_COPY, OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULC, OP_NEG, OP_PAIR, OP_SETC,
+                  OP_COPY, OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR,
+                  OP_SETC, OP_XORABC,
                   OP_SUB, R)
 
 
@@ -139,6 +140,9 @@ class CompiledCircuit:
             if op == OP_ABC:
                 keep[i] = True
                 live[dst] = live[a] = live[b] = True
+            elif op in (OP_MULABC, OP_XORABC):       # they emit a row: always kept
+                keep[i] = True
+                live[a] = live[b] = True
             elif op == OP_BITS:
                 keep[i] = True
                 live[a] = True
@@ -164,7 +168,7 @@ class CompiledCircuit:
         for i, (op, dst, a, b) in enumerate(ops):
             if op == OP_ABC:
                 last[dst] = last[a] = last[b] = i
-            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC):
                 last[a] = last[b] = i
             elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS, OP_PAIR):
                 last[a] = i
@@ -188,13 +192,15 @@ class CompiledCircuit:
                 flag = 0x100 if api.constraints[n_abc][5] else 0
                 n_abc += 1
                 prog[i] = (op | flag, slot[dst], slot[a], slot[b])
-            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC):
                 srcs = (a, b)
+                if op in (OP_MULABC, OP_XORABC):
+                    n_abc += 1
             elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
                 srcs = (a,)
             sa = slot[a] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULC, OP_ADDC, OP_NEG,
-                                   OP_INV, OP_COPY, OP_BITS) else 0
-            sb = slot[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV) else b
+                                   OP_INV, OP_COPY, OP_BITS, OP_MULABC, OP_XORABC) else 0
+            sb = slot[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC) else b
             for s in set(srcs):
                 if last.get(s) == i and s not in val_wire:
                     free.append(slot[s])
@@ -244,6 +250,17 @@ class CompiledCircuit:
                 c_.append(s[b])
                 if chk and s[d] * s[a] % R != s[b]:
                     self.last_status = -5
+            elif op == OP_MULABC:
+                a_.append(s[a])
+                b_.append(s[b])
+                s[d] = s[a] * s[b] % R
+                c_.append(s[d])
+            elif op == OP_XORABC:
+                ab2 = 2 * s[a] * s[b] % R
+                a_.append(2 * s[a] % R)
+                b_.append(s[b])
+                c_.append(ab2)
+                s[d] = (s[a] + s[b] - ab2) % R
             elif op == OP_NEG:
                 s[d] = (-s[a]) % R
             elif op == OP_SETC:
@@ -290,10 +307,12 @@ class CompiledCircuit:
         return out
 
     def fingerprint(self) -> str:
+        """Identity of the constraint system (matrices and wire layout) -- not of the witness
+        program, which may be re-scheduled without changing any proof."""
         h = hashlib.sha256()
-        for arr in (*self.L, *self.Rm, *self.O, self.program):
+        for arr in (*self.L, *self.Rm, *self.O):
             h.update(np.ascontiguousarray(arr).tobytes())
-        h.update(repr(self.consts).encode())
+        h.update(repr((self.n_wires, self.n_public, self.n_secret)).encode())
         return h.hexdigest()[:16]
 
 
