@@ -117,7 +117,7 @@ template <> struct Acc29<Fq2> {
 // ONE_BASE only changes the symbol name: the one-base launches (delta multiples in the assembly,
 // zkmi_fixed_base_mul) then show up separately from the proving-key MSMs in rocprofv3 statistics.
 template <class F, bool ONE_BASE>
-__global__ __launch_bounds__(256) void msm_accumulate(const Affine<F>* __restrict__ table,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void msm_accumulate(const Affine<F>* __restrict__ table,
                                                       const Fr* __restrict__ scalars,
                                                       const uint32_t* __restrict__ row_idx,
                                                       size_t Bp, uint32_t n, uint32_t per_chunk,

@@ -34,7 +34,8 @@ namespace zk {
 // products / inverses / integer value of F-domain elements kept in the packed canonical image
 __device__ __forceinline__ Fr fmul(const Fr& a, const Fr& b) {
   Fr r;
-  pack_canonical<Fr29Params>(r.v, mul(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
+  pack_canonical<Fr29Params>(r.v,
+                             mul_ilp(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
   return r;
 }
 __device__ __forceinline__ Fr f_one() {
@@ -50,8 +51,8 @@ __device__ Fr finv(const Fr& a) {  // a^(r-2): 0 -> 0 (gnark-crypto Element.Inve
     uint32_t e = FrParams::p(i);
     if (i == 0) e -= 2;
     for (int b = 31; b >= 0; b--) {
-      R = sqr(R);
-      if ((e >> b) & 1) R = mul(R, A);
+      R = mul_ilp(R, R);
+      if ((e >> b) & 1) R = mul_ilp(R, A);
     }
   }
   Fr r;

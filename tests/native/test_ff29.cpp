@@ -34,6 +34,8 @@ int main() {
     Fq29 X = from_std<Fq29Params>(x), Y = from_std<Fq29Params>(y), Z = from_std<Fq29Params>(z);
     CHECK(to_std(X) == x);
     CHECK(to_std(mul(X, Y)) == mul(x, y));
+    { auto m1 = mul(sub(X, Y), Z), m2 = mul_ilp(sub(X, Y), Z);
+      for (int l = 0; l < 9; l++) CHECK(m1.v[l] == m2.v[l]); }
     CHECK(to_std(sqr(X)) == sqr(x));
     // lazy combos: (x - y) * (z - x), one operand a 3-term sum normalised
     CHECK(to_std(mul(sub(X, Y), sub(Z, X))) == mul(sub(x, y), sub(z, x)));
