@@ -5,7 +5,7 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the whole prove path (witness solve -> 7 NTTs -> 4 G1 + 1 G2 MSM ->
+One step = one pass of the whole prove path (witness solve -> quotient (6 NTTs) -> 4 G1 + 1 G2 MSM ->
 assembly) over one batch of synthetic witnesses that is already resident in HBM.  Ranks are
 independent (weak scaling: every rank proves its own batch; no data-path collective).
 """
@@ -44,7 +44,7 @@ def available_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--workload", default="arbo",
@@ -217,7 +217,7 @@ def main():
                        "msm_window_tables": ctx.pk_info(prover.pk_h),
                        "parallelism": f"batch-split x{world}, no collective"},
             "pipelined": not args.no_pipeline,
-            "stage_ms": {"solve": stage[0], "quotient_7ntt": stage[1], "msm_g1": stage[2],
+            "stage_ms": {"solve": stage[0], "quotient_ntt": stage[1], "msm_g1": stage[2],
                          "msm_g2": stage[3], "assemble_overlapped": stage[4], "main_stream_span": stage[5],
                          "msm_g1_kernel_only": stage[6], "msm_g2_kernel_only": stage[7]},
             "unsatisfied": n_bad,

@@ -40,6 +40,7 @@ struct NttPlan {
   Fr* coset29_fwd = nullptr;
   Fr n_inv29;
   Fr den29;
+  Fr ninv_den;  // den / n in gnark's image: uniform post factor of the quotient's c transform
 };
 
 }  // namespace zk
