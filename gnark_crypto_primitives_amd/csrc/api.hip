@@ -403,24 +403,60 @@ static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size
                            bool may_relax, zkmi_msm_bases** out) {
   for (;;) {
     int rc = msm_bases_build(ctx, group, bases_dev, n, plan, out);
-    if (rc != ZKMI_ERR_OOM || !may_relax || plan.W >= 64) return rc;
-    plan = plan_with_windows(plan.W + 1);
+    if (rc != ZKMI_ERR_OOM || !may_relax) return rc;
+    if (plan.shared) {
+      if (plan.bits[0] <= 4) return rc;
+      plan = plan_shared(plan.bits[0] - 1);
+    } else {
+      if (plan.W >= 64) return rc;
+      plan = plan_with_windows(plan.W + 1);
+    }
   }
+}
+
+// explicit window_bits of the C-ABI: 2..16 = per-window tables, uniform width; 100 + c = one
+// shared table of c-bit signed digits per base (c in 4..16)
+static bool window_bits_ok(int wb) {
+  return wb == 0 || (wb >= 2 && wb <= 16) || (wb >= 104 && wb <= 116);
+}
+static WinPlan plan_explicit(int wb) { return wb >= 100 ? plan_shared(wb - 100) : plan_uniform(wb); }
+// auto plans: shared tables unless ZKMI_MSM_SHARED=0 asks for the per-window layout
+static bool shared_default() {
+  static const bool v = [] {
+    const char* e = getenv("ZKMI_MSM_SHARED");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+static double usable_table_bytes() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+  const double usable = (double)free_b - 32e9;   // working set of two pipeline sets + digits
+  return usable > 0 ? usable : 0.0;
 }
 
 int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
                         zkmi_msm_bases** out) {
   ZK_HIP(hipSetDevice(ctx->device));
   if (!out) return ZKMI_ERR_ARG;
-  if (window_bits != 0 && (window_bits < 2 || window_bits > 16)) {
-    ctx->err = "window_bits must be 0 (auto) or in [2,16]";
+  if (!window_bits_ok(window_bits)) {
+    ctx->err = "window_bits must be 0 (auto), in [2,16] or 100 + [4,16]";
     return ZKMI_ERR_ARG;
   }
   Staged sb(ctx);
   int rc = sb.in(bases, n * (group == 1 ? 64 : 128));
   if (rc) return rc;
-  const WinPlan plan = window_bits ? plan_uniform(window_bits)
-                                   : plan_windows_for_budget(n, group, table_budget(group));
+  WinPlan plan;
+  if (window_bits) {
+    plan = plan_explicit(window_bits);
+  } else if (shared_default()) {
+    int c1, c2;
+    plan_shared_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(), &c1,
+                           &c2);
+    plan = plan_shared(group == 1 ? c1 : c2);
+  } else {
+    plan = plan_windows_for_budget(n, group, table_budget(group));
+  }
   return bases_load_plan(ctx, group, sb.dev, n, plan, window_bits == 0, out);
 }
 
@@ -560,11 +596,20 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   int rc;
   // one window plan per group for the whole key, sized against free HBM
   const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
-  const WinPlan p1 = auto1 ? plan_windows_for_budget((size_t)d->n_a + d->n_b + d->n_k + d->n_z, 1,
-                                                     table_budget(1))
-                           : plan_uniform((int)d->window_bits_g1);
-  const WinPlan p2 = auto2 ? plan_windows_for_budget(d->n_b, 2, table_budget(2))
-                           : plan_uniform((int)d->window_bits_g2);
+  if (!window_bits_ok((int)d->window_bits_g1) || !window_bits_ok((int)d->window_bits_g2)) {
+    ctx->err = "pk: window_bits must be 0 (auto), in [2,16] or 100 + [4,16]";
+    delete pk;
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n1 = (size_t)d->n_a + d->n_b + d->n_k + d->n_z;
+  int sc1 = 0, sc2 = 0;
+  if (shared_default()) plan_shared_for_budget(n1, d->n_b, usable_table_bytes(), &sc1, &sc2);
+  const WinPlan p1 = !auto1 ? plan_explicit((int)d->window_bits_g1)
+                     : sc1  ? plan_shared(sc1)
+                            : plan_windows_for_budget(n1, 1, table_budget(1));
+  const WinPlan p2 = !auto2 ? plan_explicit((int)d->window_bits_g2)
+                     : sc2  ? plan_shared(sc2)
+                            : plan_windows_for_budget(d->n_b, 2, table_budget(2));
   auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
                   zkmi_msm_bases** out) -> int {
     Staged sb(ctx);

@@ -52,10 +52,46 @@ __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restric
   const uint32_t i = i0 + t;
   if (t >= T || i >= n) return;
   const int W = plan.W;
-  const uint32_t Dmax = 1u << (plan.bits[0] - 1);   // the widest windows come first
+  // the widest windows come first; a shared table is built in segments of 512 multiples
+  const uint32_t Dmax = plan.shared ? (plan.per_base < 512u ? plan.per_base : 512u)
+                                    : 1u << (plan.bits[0] - 1);
   F* szz = scratch + t;
   F* szzz = scratch + (size_t)Dmax * T + t;
   F* spre = scratch + (size_t)2 * Dmax * T + t;
+  if (plan.shared) {
+    // T[i][d-1] = d * P_i, d = 1..per_base: one running sum, normalised segment by segment
+    const Affine<F> P = bases[i];
+    Affine<F>* row = table + (size_t)i * plan.per_base;
+    if (P.is_inf()) {
+      for (uint32_t d = 0; d < plan.per_base; d++) row[d] = Affine<F>::inf();
+      return;
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t s0 = 0; s0 < plan.per_base; s0 += Dmax) {
+      Affine<F>* seg = row + s0;
+      F pref = F::one();
+      for (uint32_t d = 0; d < Dmax; d++) {
+        madd(acc, P);
+        seg[d].x = acc.x;
+        seg[d].y = acc.y;
+        szz[(size_t)d * T] = acc.zz;
+        szzz[(size_t)d * T] = acc.zzz;
+        spre[(size_t)d * T] = pref;
+        pref = mul(pref, acc.zzz);
+      }
+      F inv = inverse(pref);
+      for (uint32_t d = Dmax; d-- > 0;) {
+        F zzz = szzz[(size_t)d * T];
+        F izzz = mul(inv, spre[(size_t)d * T]);
+        inv = mul(inv, zzz);
+        F izz = sqr(mul(izzz, szz[(size_t)d * T]));
+        F x = mul(seg[d].x, izz), y = mul(seg[d].y, izzz);
+        seg[d].x = to_r261 ? to_r261_domain(x) : x;
+        seg[d].y = to_r261 ? to_r261_domain(y) : y;
+      }
+    }
+    return;
+  }
   Affine<F> Q = bases[i];
   for (int j = 0; j < W; j++) {
     const uint32_t D = 1u << (plan.bits[j] - 1);
@@ -158,13 +194,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   partial[(size_t)chunk * Bp + b] = to_std(acc);
 }
 
+// ---- shared-table path: one table per base, one accumulator per (window, chunk) -------------------
+// The per-window tables above spend HBM on 2^(c_j) multiples of 2^(shift_j) P for EVERY window.
+// With a single table of d * P the same HBM holds windows ~5 bits wider (c = 15 instead of ~10 for
+// the Arbo-160 key: 17 mixed additions per (base, proof) instead of 25); the price is that the
+// windows can no longer share an accumulator.  Lane = proof makes that free: the window index is a
+// third grid dimension, every (window, chunk) block keeps its own register accumulator, and the W
+// window sums of a proof are combined once per MSM with Horner's rule (255 doublings per proof,
+// not per base).
+//
+// Signed digits without a carry chain: with K = sum_j 2^(pos_j + c_j - 1) and s' = s + K, digit j
+// is ((s' >> pos_j) & (2^c_j - 1)) - 2^(c_j - 1), each in [-2^(c_j-1), 2^(c_j-1)).  One pass
+// converts the Montgomery scalars to integers and stores the digits as int16, [window][base][proof].
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars,
+                                                         const uint32_t* __restrict__ row_idx,
+                                                         size_t Bp, uint32_t n, WinPlan plan,
+                                                         Fr kmul, Fr koff,
+                                                         int16_t* __restrict__ digits) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    const uint32_t row = row_idx ? row_idx[i] : i;
+    Fr s = mul(bi_ld(scalars, row, b, Bp), kmul);   // Montgomery image -> integer (see msm_accumulate)
+    uint64_t cy = 0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      cy += (uint64_t)s.v[l] + koff.v[l];
+      s.v[l] = (uint32_t)cy;
+      cy >>= 32;
+    }
+    uint32_t pos = 0;
+    for (int j = 0; j < plan.W; j++) {
+      const uint32_t c = plan.bits[j];              // wave-uniform
+      const uint32_t w = pos >> 5, sh = pos & 31u;
+      uint32_t v = s.v[w] >> sh;
+      if (sh && w + 1 < 8) v |= s.v[w + 1] << (32u - sh);
+      const int32_t d = (int32_t)(v & ((1u << c) - 1u)) - (int32_t)(1u << (c - 1));
+      digits[((size_t)j * n + i) * Bp + b] = (int16_t)d;
+      pos += c;
+    }
+  }
+}
+
+// grid: x over proofs, y over chunks of bases, z over windows
+template <class F>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void
+msm_accumulate_shared(const Affine<F>* __restrict__ table, const int16_t* __restrict__ digits,
+                      size_t Bp, uint32_t n, uint32_t per_chunk, uint32_t per_base,
+                      XYZZ<F>* __restrict__ partial) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.y, j = blockIdx.z;
+  const uint32_t i0 = chunk * per_chunk;
+  uint32_t i1 = i0 + per_chunk;
+  if (i1 > n) i1 = n;
+  const int16_t* dj = digits + (size_t)j * n * Bp + b;
+  typename Acc29<F>::type acc = Acc29<F>::type::infinity();
+  for (uint32_t i = i0; i < i1; i++) {
+    const int32_t d = dj[(size_t)i * Bp];
+    if (d) {
+      const bool negd = d < 0;
+      const uint32_t mag = (uint32_t)(negd ? -d : d);
+      const Affine<F> e = table[(size_t)i * per_base + (mag - 1)];
+      Acc29<F>::add(acc, e, negd);
+    }
+  }
+  partial[((size_t)j * gridDim.y + chunk) * Bp + b] = to_std(acc);
+}
+
+// out[b] = sum_j 2^(pos_j) * wsum[j][b]
+template <class F>
+__global__ __launch_bounds__(64) void msm_horner(const XYZZ<F>* __restrict__ wsum, size_t Bp,
+                                                 WinPlan plan, XYZZ<F>* __restrict__ out) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  XYZZ<F> acc = wsum[(size_t)(plan.W - 1) * Bp + b];
+  for (int j = plan.W - 2; j >= 0; j--) {
+    const int c = plan.bits[j];
+    for (int k = 0; k < c; k++)
+      if (!acc.is_inf()) acc = dbl(acc);
+    const XYZZ<F> p = wsum[(size_t)j * Bp + b];
+    padd(acc, p);
+  }
+  out[b] = acc;
+}
+
 // sums groups of `group` consecutive chunk partials: out[g][b] = sum_{k < group} in[g*group + k][b]
+// (blockIdx.z selects an independent set: partial += z * in_zstride, out += z * out_zstride)
 template <class F>
 __global__ __launch_bounds__(64) void msm_reduce(const XYZZ<F>* __restrict__ partial, size_t Bp,
                                                  uint32_t chunks, uint32_t group,
-                                                 XYZZ<F>* __restrict__ out) {
+                                                 XYZZ<F>* __restrict__ out, size_t in_zstride,
+                                                 size_t out_zstride) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
+  partial += (size_t)blockIdx.z * in_zstride;
+  out += (size_t)blockIdx.z * out_zstride;
   const uint32_t k0 = blockIdx.y * group;
   uint32_t k1 = k0 + group;
   if (k1 > chunks) k1 = chunks;
@@ -213,6 +336,36 @@ WinPlan plan_uniform(int c) {   // ceil(255 / c) windows of c bits (covers >= 25
   p.per_base = off;
   return p;
 }
+WinPlan plan_shared(int c) {   // ceil(255 / c) windows over ONE table of 2^(c-1) multiples
+  WinPlan p;
+  if (c < 4) c = 4;     // at most 64 windows
+  if (c > 16) c = 16;   // digits are stored as int16
+  p.shared = 1;
+  p.W = (255 + c - 1) / c;
+  for (int j = 0; j < p.W; j++) {
+    p.bits[j] = (uint8_t)(j + 1 < p.W ? c : 255 - (p.W - 1) * c);
+    p.off[j] = 0;
+  }
+  p.per_base = 1u << (c - 1);
+  return p;
+}
+// Widths of the shared tables of a key: the (c1, c2) that minimises n1 * W(c1) + 3 * n2 * W(c2)
+// (a G2 mixed addition costs about three G1 ones) among those whose tables fit `usable_bytes`.
+void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2) {
+  double best = 1e300;
+  *c1 = *c2 = 4;
+  for (int a = 4; a <= 16; a++)
+    for (int b = 4; b <= 16; b++) {
+      const double bytes = (double)n1 * (1u << (a - 1)) * 64.0 + (double)n2 * (1u << (b - 1)) * 128.0;
+      if (bytes > usable_bytes) continue;
+      const double cost = (double)n1 * ((255 + a - 1) / a) + 3.0 * (double)n2 * ((255 + b - 1) / b);
+      if (cost < best) {
+        best = cost;
+        *c1 = a;
+        *c2 = b;
+      }
+    }
+}
 // Table budgets against free HBM: a reserve for the prover's working set (two pipeline sets of
 // value file + a, b, c, NTT scratch, MSM partials: ~25 GB at B = 1024, Arbo-160), then 64 % of the
 // rest for the G1 bases of a key and 34 % for its G2 bases.  Arbo-160 on a 288 GiB MI355X:
@@ -235,7 +388,8 @@ WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes) 
 template <class F>
 static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
-  const uint32_t D = 1u << (plan.bits[0] - 1);
+  const uint32_t D = plan.shared ? (plan.per_base < 512u ? plan.per_base : 512u)
+                                 : 1u << (plan.bits[0] - 1);
   // slab of threads sized so the inversion scratch stays under ~2 GB
   size_t per_thread = (size_t)3 * D * sizeof(F);
   size_t T = (size_t)2e9 / per_thread;
@@ -302,6 +456,66 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     kmul = from_mont(inverse(to_mont(t)));
   }
   const size_t n = bases->n;
+  if (bases->plan.shared) {
+    const WinPlan& plan = bases->plan;
+    const int W = plan.W;
+    Fr koff = Fr::zero();   // K = sum_j 2^(pos_j + c_j - 1)
+    {
+      uint32_t pos = 0;
+      for (int j = 0; j < W; j++) {
+        const uint32_t bit = pos + plan.bits[j] - 1;
+        koff.v[bit >> 5] |= 1u << (bit & 31);
+        pos += plan.bits[j];
+      }
+    }
+    // (window, chunk) blocks: 8 x the wave slots of the chip, as for the per-window tables
+    size_t chunks = (size_t)8 * 262144 / Bp / (size_t)W;
+    if (chunks < 1) chunks = 1;
+    if (chunks > n) chunks = n;
+    const uint32_t per_chunk = (uint32_t)((n + chunks - 1) / chunks);
+    chunks = (n + per_chunk - 1) / per_chunk;
+    uint32_t group = 1;
+    while ((size_t)group * group < chunks) group++;
+    const uint32_t ngroups = (uint32_t)((chunks + group - 1) / group);
+    void *partial, *digits;
+    int rc = ensure_scratch(ctx, 6, ((chunks + ngroups + 1) * W) * Bp * sizeof(XYZZ<F>), &partial);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(ctx, 12, (size_t)W * n * Bp * sizeof(int16_t), &digits))) return rc;
+    XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
+    XYZZ<F>* wsum = mid + (size_t)ngroups * W * Bp;
+    const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
+    zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
+    const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
+    if (ev >= 0) {
+      es->msm_ev_group[ev] = bases->group;
+      hipEventRecord(es->msm_ev[ev][0], ctx->stream);
+    }
+    hipLaunchKernelGGL(msm_digits_kernel,
+                       dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
+                       ctx->stream, scalars, row_idx, Bp, (uint32_t)n, plan, kmul, koff,
+                       (int16_t*)digits);
+    hipLaunchKernelGGL((msm_accumulate_shared<F>),
+                       dim3((unsigned)(Bp / bx), (unsigned)chunks, (unsigned)W), dim3(bx), 0,
+                       ctx->stream, (const Affine<F>*)bases->table, (const int16_t*)digits, Bp,
+                       (uint32_t)n, per_chunk, plan.per_base, (XYZZ<F>*)partial);
+    if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
+    if (ngroups > 1) {
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), ngroups, (unsigned)W), dim3(64),
+                         0, ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid,
+                         chunks * Bp, (size_t)ngroups * Bp);
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
+                         ctx->stream, (const XYZZ<F>*)mid, Bp, ngroups, ngroups, wsum,
+                         (size_t)ngroups * Bp, Bp);
+    } else {
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
+                         ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks,
+                         (uint32_t)chunks, wsum, chunks * Bp, Bp);
+    }
+    hipLaunchKernelGGL((msm_horner<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
+                       (const XYZZ<F>*)wsum, Bp, plan, out);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+  }
   // 8 x as many chunks as it takes to put 4 waves on every SIMD: all blocks of the coarse grid
   // run for the whole kernel, so a few occupied wave slots (the overlapped solve of the next
   // batch) or uneven clocks cost a full extra round; measured per 1024-proof batch, G1 launches:
@@ -349,12 +563,13 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   if (ngroups > 1) {
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * Bp;
     hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), ngroups), dim3(64), 0,
-                       ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid);
+                       ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid, (size_t)0, (size_t)0);
     hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0, ctx->stream,
-                       (const XYZZ<F>*)mid, Bp, ngroups, ngroups, out);
+                       (const XYZZ<F>*)mid, Bp, ngroups, ngroups, out, (size_t)0, (size_t)0);
   } else {
     hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0, ctx->stream,
-                       (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, (uint32_t)chunks, out);
+                       (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, (uint32_t)chunks, out, (size_t)0,
+                       (size_t)0);
   }
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;

@@ -87,6 +87,9 @@ struct WinPlan {
   uint32_t per_base = 0;   // table entries per base
   uint8_t bits[64] = {};
   uint32_t off[64] = {};
+  // shared = 1: ONE table d * P_i, d = 1..2^(c-1), serves every window (off[j] = 0); the windows
+  // are accumulated separately and combined with Horner's rule at the end (msm.hip)
+  uint8_t shared = 0;
 };
 
 struct zkmi_msm_bases {
@@ -180,6 +183,8 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 // scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)
 // maps base i to its scalar row.  out_xyzz: Bp accumulators.
 // scalars_f: the scalars are in the F domain (solver output) instead of gnark's image
+WinPlan plan_shared(int c);
+void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
             size_t Bp, void* out_xyzz, bool scalars_f = false);
 

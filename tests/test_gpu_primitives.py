@@ -55,7 +55,9 @@ def test_h(zk_ctx, cref, log_n):
 
 
 @pytest.mark.parametrize("group", [1, 2])
-@pytest.mark.parametrize("n,c", [(1, 4), (37, 4), (200, 7), (64, 10)])
+@pytest.mark.parametrize("n,c", [(1, 4), (37, 4), (200, 7), (64, 10),
+                                 # 100 + c: one shared table per base, per-window accumulators
+                                 (1, 104), (37, 105), (200, 107), (64, 113), (90, 116), (300, 0)])
 def test_msm(zk_ctx, cref, group, n, c):
     r = H.rng(300 + n + group)
     gen = H.g1_gen_mont() if group == 1 else H.g2_gen_mont()

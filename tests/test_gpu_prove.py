@@ -105,12 +105,13 @@ def test_invalid_witness_status(zk_ctx, poseidon_setup):
     assert np.array_equal(proofs[0], proofs[2])
 
 
-@pytest.mark.parametrize("levels,populated", [(8, 3), (24, 0)])
-def test_smt_inclusion_prove(zk_ctx, levels, populated):
+@pytest.mark.parametrize("levels,populated,wbits", [(8, 3, (7, 5)), (24, 0, (7, 5)),
+                                                    (8, 5, (109, 106)), (12, 2, (0, 0))])
+def test_smt_inclusion_prove(zk_ctx, levels, populated, wbits):
     from oracle import cref
     cc = compile_circuit(circuits.smt_inclusion_circuit(levels))
     pk, vk, td = groth16.setup(cc, 5, groth16.gpu_mul(zk_ctx))
-    prover = groth16.Prover(zk_ctx, cc, pk, window_bits_g1=7, window_bits_g2=5)
+    prover = groth16.Prover(zk_ctx, cc, pk, *wbits)
     rng = random.Random(levels)
     batch = 9
     ws = [smt_witness.synthetic_inclusion(rng, levels, populated) for _ in range(batch)]
