@@ -850,7 +850,8 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
         (rc = ensure_scratch(ctx, si == 0 ? 15 : 14, Bp * (7 * 128 + 2 * 256 + 256), &dummy)))
       return rc;
   }
-  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15, Bp * (7 * 128 + 2 * 256 + 256), &S.sums)))
+  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15, Bp * (7 * 128 + 2 * 256 + 256 + 64 * (4 * 128 + 256)),
+                           &S.sums)))
     return rc;
   S.heavy_enqueued = false;
   if ((rc = ensure_scratch(ctx, base + 0, (size_t)cs->n_slots * Bp * 32, &S.slots)) ||
@@ -900,6 +901,8 @@ struct SumsView {
   G1XYZZ *sA, *sB1, *sK, *sZ, *tR, *tS, *tNRS;
   G2XYZZ *sB2, *tS2;
   ProofOut* proofs;
+  G1XYZZ* w1[4];   // deferred window sums of A, B1, K, Z ([<= 64][Bp] each), shared-table plans
+  G2XYZZ* w2;
   SumsView(void* base, size_t Bp) {
     char* m = (char*)base;
     sA = (G1XYZZ*)m;   m += Bp * 128;
@@ -911,7 +914,12 @@ struct SumsView {
     tNRS = (G1XYZZ*)m; m += Bp * 128;
     sB2 = (G2XYZZ*)m;  m += Bp * 256;
     tS2 = (G2XYZZ*)m;  m += Bp * 256;
-    proofs = (ProofOut*)m;
+    proofs = (ProofOut*)m;  m += Bp * 256;
+    for (int i = 0; i < 4; i++) {
+      w1[i] = (G1XYZZ*)m;
+      m += 64 * Bp * 128;
+    }
+    w2 = (G2XYZZ*)m;
   }
 };
 
@@ -940,15 +948,17 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   hipEventRecord(S.evq[1], ctx->stream);
   S.msm_ev_used = 0;
   ctx->msm_ev_set = si;
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true)) ||
-      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ))) {
+  // shared-table plans: stop at the window sums, the Horner step runs with the assembly
+  const bool d1 = pk->Z->plan.shared, d2 = pk->B2->plan.shared;
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true, d1 ? v.w1[0] : nullptr)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true, d1 ? v.w1[1] : nullptr)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true, d1 ? v.w1[2] : nullptr)) ||
+      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr))) {
     ctx->msm_ev_set = -1;
     return rc;
   }
   hipEventRecord(S.evq[2], ctx->stream);
-  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true, d2 ? v.w2 : nullptr);
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);
@@ -983,6 +993,24 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
   hipStream_t q3 = ctx->stream3;
   ZK_HIP(hipStreamWaitEvent(q3, S.evq[4], 0));
   hipEventRecord(S.eva[0], q3);
+  if (pk->Z->plan.shared) {
+    void* ws[4] = {v.w1[0], v.w1[1], v.w1[2], v.w1[3]};
+    void* os[4] = {v.sA, v.sB1, v.sK, v.sZ};
+    const zkmi_msm_bases* ms[4] = {pk->A, pk->B1, pk->K, pk->Z};
+    bool same = true;   // an out-of-memory relaxation may have narrowed one table
+    for (int i = 0; i < 3; i++) same = same && ms[i]->plan.bits[0] == pk->Z->plan.bits[0];
+    if (same) {
+      if ((rc = msm_horner_run(ctx, q3, 1, pk->Z->plan, 4, ws, os, Bp))) return rc;
+    } else {
+      for (int i = 0; i < 4; i++)
+        if ((rc = msm_horner_run(ctx, q3, 1, ms[i]->plan, 1, ws + i, os + i, Bp))) return rc;
+    }
+  }
+  if (pk->B2->plan.shared) {
+    void* ws[1] = {v.w2};
+    void* os[1] = {v.sB2};
+    if ((rc = msm_horner_run(ctx, q3, 2, pk->B2->plan, 1, ws, os, Bp))) return rc;
+  }
   PkConsts pc{pk->alpha, pk->beta1, pk->beta2};
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, q3, v.sA, v.sB1, v.sK,
                      v.sZ, v.tR, v.tS, v.tNRS, (const Fr*)S.rs, Bp, pc, v.proofs);

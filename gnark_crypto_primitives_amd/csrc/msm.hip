@@ -260,12 +260,18 @@ msm_accumulate_shared(const Affine<F>* __restrict__ table, const int16_t* __rest
   partial[((size_t)j * gridDim.y + chunk) * Bp + b] = to_std(acc);
 }
 
-// out[b] = sum_j 2^(pos_j) * wsum[j][b]
+// out[b] = sum_j 2^(pos_j) * wsum[j][b]; blockIdx.y selects one of up to four independent sums
 template <class F>
-__global__ __launch_bounds__(64) void msm_horner(const XYZZ<F>* __restrict__ wsum, size_t Bp,
-                                                 WinPlan plan, XYZZ<F>* __restrict__ out) {
+struct HornerArgs {
+  const XYZZ<F>* wsum[4];
+  XYZZ<F>* out[4];
+};
+template <class F>
+__global__ __launch_bounds__(64) void msm_horner(HornerArgs<F> args, size_t Bp, WinPlan plan) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
+  const XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
+  XYZZ<F>* __restrict__ out = args.out[blockIdx.y];
   XYZZ<F> acc = wsum[(size_t)(plan.W - 1) * Bp + b];
   for (int j = plan.W - 2; j >= 0; j--) {
     const int c = plan.bits[j];
@@ -447,7 +453,8 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 
 template <class F>
 static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
-                    const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f) {
+                    const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f,
+                    XYZZ<F>* wsum_out) {
   Fr kmul = Fr::zero();
   kmul.v[0] = 1;  // plain 1: from_mont
   if (scalars_f) {  // plain 2^-5 mod r
@@ -482,7 +489,8 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     if (rc) return rc;
     if ((rc = ensure_scratch(ctx, 12, (size_t)W * n * Bp * sizeof(int16_t), &digits))) return rc;
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
-    XYZZ<F>* wsum = mid + (size_t)ngroups * W * Bp;
+    // window sums: into the caller's buffer when the Horner step is deferred (msm_horner_run)
+    XYZZ<F>* wsum = wsum_out ? wsum_out : mid + (size_t)ngroups * W * Bp;
     const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
     zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
     const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
@@ -511,10 +519,19 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
                          ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks,
                          (uint32_t)chunks, wsum, chunks * Bp, Bp);
     }
-    hipLaunchKernelGGL((msm_horner<F>), dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
-                       (const XYZZ<F>*)wsum, Bp, plan, out);
+    if (!wsum_out) {
+      HornerArgs<F> ha{};
+      ha.wsum[0] = wsum;
+      ha.out[0] = out;
+      hipLaunchKernelGGL((msm_horner<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0, ctx->stream,
+                         ha, Bp, plan);
+    }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
+  }
+  if (wsum_out) {
+    ctx->err = "msm: deferred window sums need a shared-table plan";
+    return ZKMI_ERR_ARG;
   }
   // 8 x as many chunks as it takes to put 4 waves on every SIMD: all blocks of the coarse grid
   // run for the whole kernel, so a few occupied wave slots (the overlapped solve of the next
@@ -584,8 +601,45 @@ __global__ void fill_inf_g2(G2XYZZ* out, size_t n) {
   if (i < n) out[i] = G2XYZZ::inf();
 }
 
+// Horner step of up to four deferred MSMs of one group (same plan) in one launch on `stream`
+int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& plan, int count,
+                   void* const* wsums, void* const* outs, size_t Bp) {
+  if (count < 1 || count > 4) return ZKMI_ERR_ARG;
+  if (group == 1) {
+    HornerArgs<Fq> ha{};
+    for (int i = 0; i < count; i++) {
+      ha.wsum[i] = (const G1XYZZ*)wsums[i];
+      ha.out[i] = (G1XYZZ*)outs[i];
+    }
+    hipLaunchKernelGGL((msm_horner<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
+                       stream, ha, Bp, plan);
+  } else {
+    HornerArgs<Fq2> ha{};
+    for (int i = 0; i < count; i++) {
+      ha.wsum[i] = (const G2XYZZ*)wsums[i];
+      ha.out[i] = (G2XYZZ*)outs[i];
+    }
+    hipLaunchKernelGGL((msm_horner<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
+                       stream, ha, Bp, plan);
+  }
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz, bool scalars_f) {
+            size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out) {
+  if (bases->n == 0 && wsum_out && bases->plan.shared) {
+    // deferred path: every window sum is the identity
+    const size_t cnt = (size_t)bases->plan.W * Bp;
+    if (bases->group == 1)
+      hipLaunchKernelGGL(fill_inf_g1, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream,
+                         (G1XYZZ*)wsum_out, cnt);
+    else
+      hipLaunchKernelGGL(fill_inf_g2, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream,
+                         (G2XYZZ*)wsum_out, cnt);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+  }
   if (bases->n == 0) {
     if (bases->group == 1)
       hipLaunchKernelGGL(fill_inf_g1, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream,
@@ -597,8 +651,10 @@ int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const
     return ZKMI_OK;
   }
   if (bases->group == 1)
-    return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz, scalars_f);
-  return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz, scalars_f);
+    return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz, scalars_f,
+                        (G1XYZZ*)wsum_out);
+  return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz, scalars_f,
+                       (G2XYZZ*)wsum_out);
 }
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n) {

@@ -186,7 +186,12 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 WinPlan plan_shared(int c);
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz, bool scalars_f = false);
+            size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr);
+// With wsum_out (shared-table plans only) msm_run stops at the W window sums ([W][Bp] XYZZ) and the
+// caller finishes with msm_horner_run -- 255 dependent doublings per proof, latency-bound, which
+// the prover runs on its assembly stream under the next batch's kernels.
+int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& plan, int count,
+                   void* const* wsums, void* const* outs, size_t Bp);
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n);
 
