@@ -155,7 +155,9 @@ def main():
 
     if rank == 0:
         stage /= max(args.steps, 1)
-        # ---- roofline of the dominant kernel: msm_accumulate<Fq>, four launches per step
+        # ---- roofline of the dominant kernel: the G1 accumulate kernel, four launches per step
+        # (msm_accumulate_shared<Fq> under the default shared-table plan; stage[6] spans the digit
+        # recoding pass + the accumulate launch of each MSM)
         ns = [len(pk.a_wire), len(pk.b_wire), len(pk.k_wire), pk.g1_z.shape[0]]
         alg_bytes = sum(n * 64 + B * n * 32 for n in ns)
         msm_s = stage[6] * 1e-3
@@ -170,7 +172,9 @@ def main():
                 traffic = pm["msm_g1_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {"bound": "hbm", "kernel": "msm_accumulate<Fq, false> (G1 MSMs of the key)",
+        info = ctx.pk_info(prover.pk_h)
+        kname = "msm_accumulate_shared<Fq>" if info["g1_shared"] else "msm_accumulate<Fq, false>"
+        roofline = {"bound": "hbm", "kernel": f"{kname} (G1 MSMs of the key)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
@@ -179,7 +183,6 @@ def main():
         # v_mad_u64_u32 view beside the HBM one.  1548 mads per mixed addition (csrc/ec29.h), one
         # addition per (base, window, proof); peak 3.55e13 lane-mads/s measured by
         # tools/instr_rate.hip (profiles/r01_instr_rate.log).
-        info = ctx.pk_info(prover.pk_h)
         madds = sum(ns) * info["g1_windows"] * B
         roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1548 / msm_s,
                            "peak": 3.55e13, "frac": madds * 1548 / msm_s / 3.55e13}

@@ -449,13 +449,17 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
   WinPlan plan;
   if (window_bits) {
     plan = plan_explicit(window_bits);
-  } else if (shared_default()) {
-    int c1, c2;
-    plan_shared_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(), &c1,
-                           &c2);
-    plan = plan_shared(group == 1 ? c1 : c2);
   } else {
+    // per-window tables need no Horner tail: keep them when they reach as few windows as the
+    // shared table would (small base sets); otherwise one shared table per base
     plan = plan_windows_for_budget(n, group, table_budget(group));
+    if (shared_default()) {
+      int c1, c2;
+      plan_shared_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(),
+                             &c1, &c2);
+      const WinPlan ps = plan_shared(group == 1 ? c1 : c2);
+      if (ps.W < plan.W) plan = ps;
+    }
   }
   return bases_load_plan(ctx, group, sb.dev, n, plan, window_bits == 0, out);
 }
@@ -604,12 +608,14 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   const size_t n1 = (size_t)d->n_a + d->n_b + d->n_k + d->n_z;
   int sc1 = 0, sc2 = 0;
   if (shared_default()) plan_shared_for_budget(n1, d->n_b, usable_table_bytes(), &sc1, &sc2);
-  const WinPlan p1 = !auto1 ? plan_explicit((int)d->window_bits_g1)
-                     : sc1  ? plan_shared(sc1)
-                            : plan_windows_for_budget(n1, 1, table_budget(1));
-  const WinPlan p2 = !auto2 ? plan_explicit((int)d->window_bits_g2)
-                     : sc2  ? plan_shared(sc2)
-                            : plan_windows_for_budget(d->n_b, 2, table_budget(2));
+  // auto: per-window tables when they reach as few windows as a shared table would (small keys:
+  // no Horner tail), otherwise one shared table per base
+  WinPlan p1 = auto1 ? plan_windows_for_budget(n1, 1, table_budget(1))
+                     : plan_explicit((int)d->window_bits_g1);
+  WinPlan p2 = auto2 ? plan_windows_for_budget(d->n_b, 2, table_budget(2))
+                     : plan_explicit((int)d->window_bits_g2);
+  if (auto1 && sc1 && plan_shared(sc1).W < p1.W) p1 = plan_shared(sc1);
+  if (auto2 && sc2 && plan_shared(sc2).W < p2.W) p2 = plan_shared(sc2);
   auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
                   zkmi_msm_bases** out) -> int {
     Staged sb(ctx);
@@ -654,6 +660,8 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info) {
   info[3] = pk->B2->plan.per_base;
   info[4] = pk->A->table_bytes + pk->B1->table_bytes + pk->K->table_bytes + pk->Z->table_bytes;
   info[5] = pk->B2->table_bytes;
+  info[6] = pk->Z->plan.shared;
+  info[7] = pk->B2->plan.shared;
   return ZKMI_OK;
 }
 

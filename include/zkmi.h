@@ -68,8 +68,12 @@ int zkmi_ntt_batch(zkmi_ctx* ctx, void* data, int log_n, size_t batch, int inver
 int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, void* h_out,
                  int log_n, size_t batch);
 
-/* Fixed-base MSM handle: bases are uploaded once and expanded into the HBM-resident window
- * table.  group: 1 = G1, 2 = G2.  window_bits = 0 picks a default. */
+/* Fixed-base MSM handle: bases are uploaded once and expanded into HBM-resident tables of signed
+ * window multiples.  group: 1 = G1, 2 = G2.
+ *   window_bits = 0: widest windows the free HBM allows, ONE table d*P (d = 1..2^(c-1)) per base
+ *                    shared by all windows, per-window accumulators combined by Horner's rule;
+ *   100 + c (c in 4..16): that layout with an explicit width;
+ *   c in 2..16: the per-window layout (a table d*2^(c*j)*P for every window j, one accumulator). */
 typedef struct zkmi_msm_bases zkmi_msm_bases;
 int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
                         zkmi_msm_bases** out);
@@ -104,7 +108,7 @@ typedef struct {
   const void* g1_delta;
   const void* g2_beta;
   const void* g2_delta;
-  uint32_t window_bits_g1; /* 0 = default */
+  uint32_t window_bits_g1; /* as zkmi_msm_bases_load: 0 = default */
   uint32_t window_bits_g2;
 } zkmi_pk_desc;
 /* Copies the key to the device and builds the MSM window tables; host buffers may be freed
@@ -113,8 +117,8 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* desc, zkmi_pk** out);
 void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk);
 /* Window plan chosen for the key: info[0] = windows per G1 scalar, [1] = table entries per G1
  * base, [2] = windows per G2 scalar, [3] = table entries per G2 base, [4] = G1 table bytes (all
- * four MSMs), [5] = G2 table bytes. */
-int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 6 */);
+ * four MSMs), [5] = G2 table bytes, [6] / [7] = 1 when the G1 / G2 tables are shared-table plans. */
+int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 8 */);
 
 /* -- constraint system (witness program) ----------------------------------------------------- */
 /* What cs.R1CS.Solve needs, in the straight-line form produced by

@@ -1,5 +1,4 @@
 #!/bin/bash
-# secondary configurations of BASELINE.json through bench.py --workload
 set -e
 out=gpurun_out/configs
 mkdir -p $out
@@ -7,5 +6,3 @@ run() { name=$1; shift; timeout -k 10 400 python bench.py --workload $name --cpu
 run poseidon --batch 8192 --distinct 256
 run elgamal-add --batch 8192 --distinct 128
 run elgamal-encrypt --batch 4096 --distinct 64
-run verifier --batch 1024
-run address --batch 512 --distinct 32
