@@ -156,8 +156,8 @@ def main():
     if rank == 0:
         stage /= max(args.steps, 1)
         # ---- roofline of the dominant kernel: the G1 accumulate kernel, four launches per step
-        # (msm_accumulate_shared<Fq> under the default shared-table plan; stage[6] spans the digit
-        # recoding pass + the accumulate launch of each MSM)
+        # (msm_accumulate_shared<Fq> under the default shared-table plan; stage[6] = sum of the HIP
+        # event pairs that bracket each accumulate launch alone)
         ns = [len(pk.a_wire), len(pk.b_wire), len(pk.k_wire), pk.g1_z.shape[0]]
         alg_bytes = sum(n * 64 + B * n * 32 for n in ns)
         msm_s = stage[6] * 1e-3

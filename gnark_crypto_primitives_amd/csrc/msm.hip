@@ -494,14 +494,14 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
     zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
     const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
-    if (ev >= 0) {
-      es->msm_ev_group[ev] = bases->group;
-      hipEventRecord(es->msm_ev[ev][0], ctx->stream);
-    }
     hipLaunchKernelGGL(msm_digits_kernel,
                        dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
                        ctx->stream, scalars, row_idx, Bp, (uint32_t)n, plan, kmul, koff,
                        (int16_t*)digits);
+    if (ev >= 0) {   // the event pair brackets the accumulate launch alone (zkmi_last_timings [6], [7])
+      es->msm_ev_group[ev] = bases->group;
+      hipEventRecord(es->msm_ev[ev][0], ctx->stream);
+    }
     hipLaunchKernelGGL((msm_accumulate_shared<F>),
                        dim3((unsigned)(Bp / bx), (unsigned)chunks, (unsigned)W), dim3(bx), 0,
                        ctx->stream, (const Affine<F>*)bases->table, (const int16_t*)digits, Bp,
