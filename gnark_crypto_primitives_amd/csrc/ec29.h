@@ -38,7 +38,24 @@ ZK_HD void mdbl29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
 
 // acc += (qx, qy); the addend is a finite point, canonical x in [0,p), y possibly negated
 // limb-wise (|limbs| < 2^29).
+// The accumulator is loop-carried in the MSM kernels.  LLVM proves at IR level that its masked limbs
+// are non-negative and rewrites their sign extensions as zero extensions, but instruction selection
+// works per basic block and cannot see that proof: a product of such a limb with a signed limb is
+// then expanded into two v_mad_u64_u32 plus two moves instead of one v_mad_i64_i32 (96 extra mads
+// and 192 moves per G1 mixed addition).  Passing the limbs through an empty asm hides the range, so
+// every product stays a signed 32 x 32 -> 64 multiply-add.
+ZK_HD void opaque_limbs(Fq29& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i < 9; i++) asm volatile("" : "+v"(a.v[i]));
+#endif
+}
+
 ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
+  opaque_limbs(acc.x);
+  opaque_limbs(acc.y);
+  opaque_limbs(acc.zz);
+  opaque_limbs(acc.zzz);
   if (acc.inf) {
     acc.x = qx;
     acc.y = norm(qy);
@@ -102,6 +119,14 @@ ZK_HD void mdbl29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
 
 // qx canonical components, qy canonical or limb-wise negated
 ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
+  opaque_limbs(acc.x.c0);    // see the G1 madd29
+  opaque_limbs(acc.x.c1);
+  opaque_limbs(acc.y.c0);
+  opaque_limbs(acc.y.c1);
+  opaque_limbs(acc.zz.c0);
+  opaque_limbs(acc.zz.c1);
+  opaque_limbs(acc.zzz.c0);
+  opaque_limbs(acc.zzz.c1);
   if (acc.inf) {
     acc.x = qx;
     acc.y = norm(qy);
