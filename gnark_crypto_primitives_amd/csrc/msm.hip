@@ -209,12 +209,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars,
                                                          const uint32_t* __restrict__ row_idx,
                                                          size_t Bp, uint32_t n, WinPlan plan,
-                                                         Fr kmul, Fr koff,
+                                                         int32_t kmul32, Fr koff,
                                                          int16_t* __restrict__ digits) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
     const uint32_t row = row_idx ? row_idx[i] : i;
-    Fr s = mul(bi_ld(scalars, row, b, Bp), kmul);   // Montgomery image -> integer (see msm_accumulate)
+    // Montgomery image -> integer on the 29-bit form: x*2^256 * 32 / 2^261 (gnark's image) or
+    // x*2^261 * 1 / 2^261 (the solver's)
+    Fr29 k = Fr29::zero();
+    k.v[0] = kmul32;
+    const Fr raw = bi_ld(scalars, row, b, Bp);
+    Fr s;
+    pack_canonical<Fr29Params>(s.v, mul(unpack29<Fr29Params>(raw.v), k));
     uint64_t cy = 0;
 #pragma unroll
     for (int l = 0; l < 8; l++) {
@@ -496,8 +502,8 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
     hipLaunchKernelGGL(msm_digits_kernel,
                        dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
-                       ctx->stream, scalars, row_idx, Bp, (uint32_t)n, plan, kmul, koff,
-                       (int16_t*)digits);
+                       ctx->stream, scalars, row_idx, Bp, (uint32_t)n, plan,
+                       (int32_t)(scalars_f ? 1 : 32), koff, (int16_t*)digits);
     if (ev >= 0) {   // the event pair brackets the accumulate launch alone (zkmi_last_timings [6], [7])
       es->msm_ev_group[ev] = bases->group;
       hipEventRecord(es->msm_ev[ev][0], ctx->stream);
