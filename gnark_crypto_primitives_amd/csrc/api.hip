@@ -431,7 +431,15 @@ static bool shared_default() {
 static double usable_table_bytes() {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  const double usable = (double)free_b - 32e9;   // working set of two pipeline sets + digits
+  // reserve for the prover's working set (two pipeline sets of value file + a, b, c, NTT scratch,
+  // MSM digits and partials: ~23 GB at B = 1024 on the Arbo-160 circuit).  Bigger batches or
+  // circuits need more: ZKMI_TABLE_RESERVE_GB.
+  static const double reserve = [] {
+    const char* e = getenv("ZKMI_TABLE_RESERVE_GB");
+    const double v = e ? atof(e) : 32.0;
+    return (v < 1.0 ? 1.0 : v) * 1e9;
+  }();
+  const double usable = (double)free_b - reserve;
   return usable > 0 ? usable : 0.0;
 }
 
