@@ -241,14 +241,16 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ 
   }
 }
 
-// grid: x over proofs, y over chunks of bases, z over windows
+// grid: x over proofs, y over windows, z over chunks of bases (all windows of a chunk are dispatched
+// together, so the blocks that walk the same tables run at the same time)
 template <class F>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void
 msm_accumulate_shared(const Affine<F>* __restrict__ table, const int16_t* __restrict__ digits,
                       size_t Bp, uint32_t n, uint32_t per_chunk, uint32_t per_base,
                       XYZZ<F>* __restrict__ partial) {
+  // (an XCD-aware deal of the chunks -- all blocks of a chunk on one L2 -- measured no better)
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t chunk = blockIdx.y, j = blockIdx.z;
+  const uint32_t chunk = blockIdx.z, j = blockIdx.y;
   const uint32_t i0 = chunk * per_chunk;
   uint32_t i1 = i0 + per_chunk;
   if (i1 > n) i1 = n;
@@ -263,7 +265,7 @@ msm_accumulate_shared(const Affine<F>* __restrict__ table, const int16_t* __rest
       Acc29<F>::add(acc, e, negd);
     }
   }
-  partial[((size_t)j * gridDim.y + chunk) * Bp + b] = to_std(acc);
+  partial[((size_t)j * gridDim.z + chunk) * Bp + b] = to_std(acc);
 }
 
 // out[b] = sum_j 2^(pos_j) * wsum[j][b]; blockIdx.y selects one of up to four independent sums
@@ -482,7 +484,12 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
       }
     }
     // (window, chunk) blocks: 8 x the wave slots of the chip, as for the per-window tables
-    size_t chunks = (size_t)8 * 262144 / Bp / (size_t)W;
+    static const size_t shared_factor = [] {
+      const char* e = getenv("ZKMI_MSM_CHUNKS");
+      const long v = e ? atol(e) : 8;
+      return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    size_t chunks = shared_factor * 262144 / Bp / (size_t)W;
     if (chunks < 1) chunks = 1;
     if (chunks > n) chunks = n;
     const uint32_t per_chunk = (uint32_t)((n + chunks - 1) / chunks);
@@ -509,7 +516,7 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
       hipEventRecord(es->msm_ev[ev][0], ctx->stream);
     }
     hipLaunchKernelGGL((msm_accumulate_shared<F>),
-                       dim3((unsigned)(Bp / bx), (unsigned)chunks, (unsigned)W), dim3(bx), 0,
+                       dim3((unsigned)(Bp / bx), (unsigned)W, (unsigned)chunks), dim3(bx), 0,
                        ctx->stream, (const Affine<F>*)bases->table, (const int16_t*)digits, Bp,
                        (uint32_t)n, per_chunk, plan.per_base, (XYZZ<F>*)partial);
     if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
