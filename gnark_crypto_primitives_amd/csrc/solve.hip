@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         const Fr va = LD(x), vb = LD(y);
         const Fr vc = fmul(va, vb);
         ST(d, vc);
-        bi_st(a, k, lane, Bp, va);
-        bi_st(b, k, lane, Bp, vb);
-        bi_st(c, k, lane, Bp, vc);
+        bi_st_nt(a, k, lane, Bp, va);
+        bi_st_nt(b, k, lane, Bp, vb);
+        bi_st_nt(c, k, lane, Bp, vc);
         k++;
         break;
       }
@@ -165,17 +165,17 @@ __global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ pr
         const Fr ab = fmul(va, vb);
         const Fr ab2 = add(ab, ab);
         ST(d, sub(add(va, vb), ab2));
-        bi_st(a, k, lane, Bp, add(va, va));
-        bi_st(b, k, lane, Bp, vb);
-        bi_st(c, k, lane, Bp, ab2);
+        bi_st_nt(a, k, lane, Bp, add(va, va));
+        bi_st_nt(b, k, lane, Bp, vb);
+        bi_st_nt(c, k, lane, Bp, ab2);
         k++;
         break;
       }
       case OP_ABC: {
         const Fr va = LD(d), vb = LD(x), vc = LD(y);
-        bi_st(a, k, lane, Bp, va);
-        bi_st(b, k, lane, Bp, vb);
-        bi_st(c, k, lane, Bp, vc);
+        bi_st_nt(a, k, lane, Bp, va);
+        bi_st_nt(b, k, lane, Bp, vb);
+        bi_st_nt(c, k, lane, Bp, vc);
         if (ins.x & 0x100u) {
           if (fmul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
         }

@@ -134,6 +134,15 @@ __device__ __forceinline__ void bi_st(Fr* base, size_t row, size_t b, size_t Bp,
   p[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
   p[Bp] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
+// write-once streams (the solver's a, b, c rows): non-temporal, so that they do not evict the MSM
+// table lines the kernels running beside the solve are hitting in L2 / Infinity Cache
+__device__ __forceinline__ void bi_st_nt(Fr* base, size_t row, size_t b, size_t Bp, const Fr& x) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* p = reinterpret_cast<u32x4*>(base) + row * 2 * Bp + b;
+  u32x4 lo = {x.v[0], x.v[1], x.v[2], x.v[3]}, hi = {x.v[4], x.v[5], x.v[6], x.v[7]};
+  __builtin_nontemporal_store(lo, p);
+  __builtin_nontemporal_store(hi, p + Bp);
+}
 #endif
 
 // witness-program opcodes (frontend/api.py)
