@@ -479,6 +479,7 @@ void zkmi_msm_bases_free(zkmi_ctx* ctx, zkmi_msm_bases* b) {
     hipStreamSynchronize(ctx->stream);
   }
   if (b->table) hipFree(b->table);
+  if (b->inf) hipFree(b->inf);
   delete b;
 }
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                       const uint32_t* __restrict__ row_idx,
                                                       size_t Bp, uint32_t n, uint32_t per_chunk,
                                                       WinPlan plan, XYZZ<F>* __restrict__ partial,
-                                                      Fr kmul) {
+                                                      Fr kmul, const uint8_t* __restrict__ inf) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t chunk = blockIdx.y;
   const uint32_t i0 = chunk * per_chunk;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
   const int W = plan.W;
   typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t i = i0; i < i1; i++) {
+    if (inf[i]) continue;   // wave-uniform: the point at infinity contributes nothing
     const uint32_t row = row_idx ? row_idx[i] : i;
     // Montgomery image -> integer: product by the plain constant 1 (gnark's x*2^256) or by
     // 2^-5 (the solver's x*2^261)
@@ -210,9 +211,14 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ 
                                                          const uint32_t* __restrict__ row_idx,
                                                          size_t Bp, uint32_t n, WinPlan plan,
                                                          int32_t kmul32, Fr koff,
+                                                         const uint8_t* __restrict__ inf,
                                                          int16_t* __restrict__ digits) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    if (inf[i]) {   // wave-uniform: the point at infinity contributes nothing
+      for (int j = 0; j < plan.W; j++) digits[((size_t)j * n + i) * Bp + b] = 0;
+      continue;
+    }
     const uint32_t row = row_idx ? row_idx[i] : i;
     // Montgomery image -> integer on the 29-bit form: x*2^256 * 32 / 2^261 (gnark's image) or
     // x*2^261 * 1 / 2^261 (the solver's)
@@ -399,6 +405,15 @@ WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes) 
   return plan_with_windows(64);
 }
 
+// inf[i] = 1 when base i is the point at infinity: its table rows are zeros and must never reach a
+// mixed addition (the digit pass / the accumulate loop skip the base)
+template <class F>
+__global__ void msm_inf_flags(const Affine<F>* __restrict__ bases, uint32_t n,
+                              uint8_t* __restrict__ inf) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inf[i] = bases[i].is_inf() ? 1 : 0;
+}
+
 template <class F>
 static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
@@ -447,11 +462,24 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
     delete b;
     return ZKMI_ERR_OOM;
   }
+  if (hipMalloc(&b->inf, n) != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(b->table);
+    delete b;
+    return ZKMI_ERR_OOM;
+  }
+  if (group == 1)
+    hipLaunchKernelGGL((msm_inf_flags<Fq>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (const G1Affine*)bases_dev, (uint32_t)n, b->inf);
+  else
+    hipLaunchKernelGGL((msm_inf_flags<Fq2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (const G2Affine*)bases_dev, (uint32_t)n, b->inf);
   int rc = group == 1
                ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table)
                : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan, (G2Affine*)b->table);
   if (rc) {
     hipFree(b->table);
+    hipFree(b->inf);
     delete b;
     return rc;
   }
@@ -510,7 +538,8 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     hipLaunchKernelGGL(msm_digits_kernel,
                        dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
                        ctx->stream, scalars, row_idx, Bp, (uint32_t)n, plan,
-                       (int32_t)(scalars_f ? 1 : 32), koff, (int16_t*)digits);
+                       (int32_t)(scalars_f ? 1 : 32), koff, (const uint8_t*)bases->inf,
+                       (int16_t*)digits);
     if (ev >= 0) {   // the event pair brackets the accumulate launch alone (zkmi_last_timings [6], [7])
       es->msm_ev_group[ev] = bases->group;
       hipEventRecord(es->msm_ev[ev][0], ctx->stream);
@@ -580,11 +609,13 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   if (n == 1)
     hipLaunchKernelGGL((msm_accumulate<F, true>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul,
+                       (const uint8_t*)bases->inf);
   else
     hipLaunchKernelGGL((msm_accumulate<F, false>), dim3((unsigned)(Bp / bx), (unsigned)chunks),
                        dim3(bx), 0, ctx->stream, (const Affine<F>*)bases->table, scalars, row_idx,
-                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul);
+                       Bp, (uint32_t)n, per_chunk, bases->plan, (XYZZ<F>*)partial, kmul,
+                       (const uint8_t*)bases->inf);
   if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
   // two-level sum of the per-chunk partials (sqrt(chunks) groups) keeps the tail parallel
   uint32_t group = 1;

@@ -98,6 +98,7 @@ struct zkmi_msm_bases {
   WinPlan plan;
   void* table = nullptr;  // affine entries [(i * W + j) << (c-1) | (d-1)]
   size_t table_bytes = 0;
+  uint8_t* inf = nullptr;  // device, n flags: base i is the point at infinity (skipped)
 };
 
 struct zkmi_pk {

@@ -95,3 +95,46 @@ def test_fixed_base_mul(zk_ctx, cref, group):
 def test_field_mul_bench_reports(zk_ctx):
     rate = zk_ctx.field_mul_bench(1, 1 << 18, 64)
     assert rate > 1e9
+
+
+@pytest.mark.parametrize("c", [6, 106])
+def test_msm_edge_cases(zk_ctx, cref, c):
+    """Infinity among the bases, extreme scalars (0, 1, r-1, r-2, 2^253), batch sizes around the
+    64-lane padding (1, 63, 64, 65), and an empty batch -- both table layouts."""
+    r = H.rng(555)
+    n = 24
+    ks = [r.randrange(1, H.R) for _ in range(n)]
+    bases = cref.batch_mul(1, H.g1_gen_mont(), H.to_mont_array(ks))
+    bases[5] = 0                                  # the point at infinity: contributes nothing
+    bases[9] = 0
+    h = zk_ctx.msm_bases_load(1, bases, n, c)
+    extreme = [0, 1, H.R - 1, H.R - 2, 1 << 253, (1 << 253) - 1, 32767, 32768, 32769, 65535, 65536]
+    for batch in (1, 63, 64, 65):
+        rows = []
+        for p in range(batch):
+            row = [r.randrange(H.R) for _ in range(n)]
+            for k in range(n):
+                if (p + k) % 3 == 0:
+                    row[k] = extreme[(p * 7 + k) % len(extreme)]
+            rows.append(H.to_mont_array(row))
+        sc = np.stack(rows)
+        want = np.stack([cref.msm(1, bases, sc[i], naive=True) for i in range(batch)])
+        out = np.zeros((batch, 8), dtype=np.uint64)
+        zk_ctx.msm_batch(h, sc, batch, out)
+        assert np.array_equal(out, want)
+    zk_ctx.msm_batch(h, np.zeros((0, n, 4), dtype=np.uint64), 0, np.zeros((0, 8), dtype=np.uint64))
+    zk_ctx.msm_bases_free(h)
+    # no bases at all: every sum is the point at infinity
+    h0 = zk_ctx.msm_bases_load(1, np.zeros((0, 8), dtype=np.uint64), 0, c)
+    out = np.ones((3, 8), dtype=np.uint64)
+    zk_ctx.msm_batch(h0, np.zeros((3, 0, 4), dtype=np.uint64), 3, out)
+    assert not out.any()
+    zk_ctx.msm_bases_free(h0)
+
+
+def test_empty_batches(zk_ctx):
+    e = np.zeros((0, 16, 4), dtype=np.uint64)
+    zk_ctx.ntt_batch(e, 4, 0)
+    zk_ctx.h_batch(e, e, e, e.copy(), 4, 0)
+    zk_ctx.fixed_base_mul(1, H.g1_gen_mont(), np.zeros((0, 4), dtype=np.uint64), 0,
+                          np.zeros((0, 8), dtype=np.uint64))

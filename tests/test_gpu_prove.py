@@ -279,3 +279,20 @@ def test_config5_secp256k1_address(zk_ctx):
     asg[3] = dict(asg[3], Address=asg[2]["Address"])      # someone else's address -> unsatisfied
     status = _prove_and_check(zk_ctx, cc, asg, 5, wbits=(5, 4))
     assert list(status != 0) == [False, False, False, True]
+
+
+def test_prove_empty_and_single(zk_ctx, poseidon_setup):
+    """batch = 0 is a no-op; batch = 1 (63 padding lanes) equals the same proof inside a batch."""
+    from oracle import pyref
+    cc, pk, vk, td, prover = poseidon_setup
+    n_in = cc.n_public - 1 + cc.n_secret
+    proofs, status = prover.prove(np.zeros((0, n_in, 4), dtype=np.uint64),
+                                  np.zeros((0, 2, 4), dtype=np.uint64))
+    assert proofs.shape == (0, 32) and status.shape == (0,)
+    inp = np.stack([to_mont_array(cc.assignment_vector({"Data": d, "Hash": pyref.poseidon_hash([d])}))
+                    for d in (11, 12, 13)])
+    rs = np.stack([to_mont_array([5 + i, 9 + i]) for i in range(3)])
+    many, st = prover.prove(inp, rs)
+    one, st1 = prover.prove(inp[1:2], rs[1:2])
+    assert not st.any() and not st1.any()
+    assert np.array_equal(one[0], many[1])
