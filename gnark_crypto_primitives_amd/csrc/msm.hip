@@ -38,96 +38,71 @@ ZK_HD Fq to_r261_domain(const Fq& x) {
 ZK_HD Fq2 to_r261_domain(const Fq2& x) { return Fq2{to_r261_domain(x.c0), to_r261_domain(x.c1)}; }
 
 // ---- table construction ------------------------------------------------------------------------
-// One thread per base, windows in sequence.  Per window: D = 2^(c-1) running mixed additions into
-// XYZZ, then one Montgomery batch inversion over the D denominators (scratch is interleaved across
-// threads so lanes touch adjacent addresses), then 2^c * Q for the next window (c = that window's
-// width, WinPlan).
+// One thread per table row: (base) for a shared table, (base, window) for per-window tables, whose
+// first entry Q = 2^(shift_j) P is reached by shift_j doublings.  A row is a running sum
+// d * Q, d = 1..D, in XYZZ, made affine in segments of at most 512 entries with one Montgomery
+// batch inversion per segment (the scratch is interleaved across threads so that lanes touch
+// adjacent addresses).  Entries are stored as x*2^261, y*2^261 (canonical): the accumulate kernels
+// work in the 2^261 domain of ff29.h and only unpack limbs.
 template <class F>
 __global__ __launch_bounds__(64) void msm_build_table(const Affine<F>* __restrict__ bases,
-                                                      uint32_t i0, uint32_t n, WinPlan plan,
+                                                      uint64_t r0, uint64_t n_rows, WinPlan plan,
                                                       Affine<F>* __restrict__ table,
                                                       F* __restrict__ scratch, uint32_t T,
-                                                      int to_r261) {
+                                                      uint32_t seg_len, int to_r261) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t i = i0 + t;
-  if (t >= T || i >= n) return;
-  const int W = plan.W;
-  // the widest windows come first; a shared table is built in segments of 512 multiples
-  const uint32_t Dmax = plan.shared ? (plan.per_base < 512u ? plan.per_base : 512u)
-                                    : 1u << (plan.bits[0] - 1);
+  const uint64_t r = r0 + t;
+  if (t >= T || r >= n_rows) return;
   F* szz = scratch + t;
-  F* szzz = scratch + (size_t)Dmax * T + t;
-  F* spre = scratch + (size_t)2 * Dmax * T + t;
+  F* szzz = scratch + (size_t)seg_len * T + t;
+  F* spre = scratch + (size_t)2 * seg_len * T + t;
+  uint32_t D;
+  Affine<F>* row;
+  Affine<F> Q;
   if (plan.shared) {
-    // T[i][d-1] = d * P_i, d = 1..per_base: one running sum, normalised segment by segment
-    const Affine<F> P = bases[i];
-    Affine<F>* row = table + (size_t)i * plan.per_base;
-    if (P.is_inf()) {
-      for (uint32_t d = 0; d < plan.per_base; d++) row[d] = Affine<F>::inf();
-      return;
+    D = plan.per_base;
+    row = table + (size_t)r * plan.per_base;
+    Q = bases[r];
+  } else {
+    const uint32_t i = (uint32_t)(r / (uint32_t)plan.W), j = (uint32_t)(r % (uint32_t)plan.W);
+    D = 1u << (plan.bits[j] - 1);
+    row = table + (size_t)i * plan.per_base + plan.off[j];
+    Q = bases[i];
+    if (!Q.is_inf() && j) {
+      uint32_t shift = 0;
+      for (uint32_t k = 0; k < j; k++) shift += plan.bits[k];
+      XYZZ<F> a = XYZZ<F>::from_affine(Q);
+      for (uint32_t k = 0; k < shift; k++) a = dbl(a);
+      Q = to_affine(a);
     }
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t s0 = 0; s0 < plan.per_base; s0 += Dmax) {
-      Affine<F>* seg = row + s0;
-      F pref = F::one();
-      for (uint32_t d = 0; d < Dmax; d++) {
-        madd(acc, P);
-        seg[d].x = acc.x;
-        seg[d].y = acc.y;
-        szz[(size_t)d * T] = acc.zz;
-        szzz[(size_t)d * T] = acc.zzz;
-        spre[(size_t)d * T] = pref;
-        pref = mul(pref, acc.zzz);
-      }
-      F inv = inverse(pref);
-      for (uint32_t d = Dmax; d-- > 0;) {
-        F zzz = szzz[(size_t)d * T];
-        F izzz = mul(inv, spre[(size_t)d * T]);
-        inv = mul(inv, zzz);
-        F izz = sqr(mul(izzz, szz[(size_t)d * T]));
-        F x = mul(seg[d].x, izz), y = mul(seg[d].y, izzz);
-        seg[d].x = to_r261 ? to_r261_domain(x) : x;
-        seg[d].y = to_r261 ? to_r261_domain(y) : y;
-      }
-    }
+  }
+  if (Q.is_inf()) {
+    for (uint32_t d = 0; d < D; d++) row[d] = Affine<F>::inf();
     return;
   }
-  Affine<F> Q = bases[i];
-  for (int j = 0; j < W; j++) {
-    const uint32_t D = 1u << (plan.bits[j] - 1);
-    Affine<F>* row = table + (size_t)i * plan.per_base + plan.off[j];
-    if (Q.is_inf()) {
-      for (uint32_t d = 0; d < D; d++) row[d] = Affine<F>::inf();
-      continue;
-    }
-    XYZZ<F> acc = XYZZ<F>::inf();
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t s0 = 0; s0 < D; s0 += seg_len) {
+    Affine<F>* seg = row + s0;
+    const uint32_t len = D - s0 < seg_len ? D - s0 : seg_len;
     F pref = F::one();
-    for (uint32_t d = 0; d < D; d++) {
+    for (uint32_t d = 0; d < len; d++) {
       madd(acc, Q);
-      row[d].x = acc.x;
-      row[d].y = acc.y;
+      seg[d].x = acc.x;
+      seg[d].y = acc.y;
       szz[(size_t)d * T] = acc.zz;
       szzz[(size_t)d * T] = acc.zzz;
       spre[(size_t)d * T] = pref;
       pref = mul(pref, acc.zzz);
     }
     F inv = inverse(pref);
-    for (uint32_t d = D; d-- > 0;) {
+    for (uint32_t d = len; d-- > 0;) {
       F zzz = szzz[(size_t)d * T];
       F izzz = mul(inv, spre[(size_t)d * T]);
       inv = mul(inv, zzz);
       F izz = sqr(mul(izzz, szz[(size_t)d * T]));
-      row[d].x = mul(row[d].x, izz);
-      row[d].y = mul(row[d].y, izzz);
-    }
-    if (j + 1 < W) Q = to_affine(dbl_affine(row[D - 1]));
-    // the tables feed msm_accumulate_f29: store x*2^261, y*2^261 (canonical) instead of the
-    // R = 2^256 Montgomery image, so the inner loop only unpacks limbs
-    if (to_r261) {
-      for (uint32_t d = 0; d < D; d++) {
-        row[d].x = to_r261_domain(row[d].x);
-        row[d].y = to_r261_domain(row[d].y);
-      }
+      F x = mul(seg[d].x, izz), y = mul(seg[d].y, izzz);
+      seg[d].x = to_r261 ? to_r261_domain(x) : x;
+      seg[d].y = to_r261 ? to_r261_domain(y) : y;
     }
   }
 }
@@ -417,21 +392,21 @@ __global__ void msm_inf_flags(const Affine<F>* __restrict__ bases, uint32_t n,
 template <class F>
 static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
-  const uint32_t D = plan.shared ? (plan.per_base < 512u ? plan.per_base : 512u)
-                                 : 1u << (plan.bits[0] - 1);
+  const uint32_t Dmax = plan.shared ? plan.per_base : 1u << (plan.bits[0] - 1);
+  const uint32_t seg_len = Dmax < 512u ? Dmax : 512u;
+  const uint64_t n_rows = plan.shared ? (uint64_t)n : (uint64_t)n * (uint64_t)plan.W;
   // slab of threads sized so the inversion scratch stays under ~2 GB
-  size_t per_thread = (size_t)3 * D * sizeof(F);
+  const size_t per_thread = (size_t)3 * seg_len * sizeof(F);
   size_t T = (size_t)2e9 / per_thread;
-  if (T > n) T = n;
+  if (T > n_rows) T = (size_t)n_rows;
   T = round_up(T, 64);
-  if (T > 65536) T = 65536;
+  if (T > 262144) T = 262144;
   void* scratch;
   int rc = ensure_scratch(ctx, 7, per_thread * T, &scratch);
   if (rc) return rc;
-  for (size_t i0 = 0; i0 < n; i0 += T) {
+  for (uint64_t r0 = 0; r0 < n_rows; r0 += T) {
     hipLaunchKernelGGL((msm_build_table<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
-                       bases_dev, (uint32_t)i0, (uint32_t)n, plan, table, (F*)scratch,
-                       (uint32_t)T, 1);
+                       bases_dev, r0, n_rows, plan, table, (F*)scratch, (uint32_t)T, seg_len, 1);
   }
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipStreamSynchronize(ctx->stream));

@@ -296,3 +296,34 @@ def test_prove_empty_and_single(zk_ctx, poseidon_setup):
     one, st1 = prover.prove(inp[1:2], rs[1:2])
     assert not st.any() and not st1.any()
     assert np.array_equal(one[0], many[1])
+
+
+@pytest.mark.parametrize("wbits", [(7, 5), (105, 104), (0, 0)])
+def test_degenerate_circuits(zk_ctx, wbits):
+    """Smallest possible keys: one linear constraint between public inputs (no private wire at all:
+    the K MSM is empty), and one product with a single internal wire (domain 2^1 / 2^0 edge)."""
+    from gnark_crypto_primitives_amd.frontend import Public
+
+    class Linear:
+        X = Public()
+        Y = Public()
+
+        def define(self, api):
+            api.AssertIsEqual(api.Add(self.X, 3), self.Y)
+
+    class Square:
+        X = Public()
+        Y = Public()
+
+        def define(self, api):
+            api.AssertIsEqual(api.Mul(self.X, self.X), self.Y)
+
+    cc = compile_circuit(Linear())
+    assert cc.n_wires == 3
+    status = _prove_and_check(zk_ctx, cc, [{"X": 4, "Y": 7}, {"X": 0, "Y": 3}, {"X": 1, "Y": 5}],
+                              21, wbits)
+    assert list(status != 0) == [False, False, True]
+    cc = compile_circuit(Square())
+    status = _prove_and_check(zk_ctx, cc, [{"X": 4, "Y": 16}, {"X": H.R - 1, "Y": 1},
+                                           {"X": 2, "Y": 5}], 22, wbits)
+    assert list(status != 0) == [False, False, True]
