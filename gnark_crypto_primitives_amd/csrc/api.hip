@@ -267,6 +267,7 @@ void zkmi_destroy(zkmi_ctx* ctx) {
     hipFree(p.tw29_fwd);
     hipFree(p.tw29_inv);
     hipFree(p.coset29_fwd);
+    hipFree(p.coset29n_fwd);
   }
   for (auto& s : ctx->scratch)
     if (s.p) hipFree(s.p);

@@ -38,6 +38,7 @@ struct NttPlan {
   Fr* tw29_fwd = nullptr;
   Fr* tw29_inv = nullptr;
   Fr* coset29_fwd = nullptr;
+  Fr* coset29n_fwd = nullptr;  // g^i / n (F domain): scaling between a fused iNTT -> coset NTT
   Fr n_inv29;
   Fr den29;
   Fr ninv_den;  // den / n in gnark's image: uniform post factor of the quotient's c transform
