@@ -85,6 +85,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+    if world > 1:
+        # first collective now: RCCL's buffers are allocated before the MSM tables size themselves
+        # against the free HBM
+        t = torch.zeros(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(t)
+        if cdev.type == "cuda":
+            torch.cuda.synchronize()
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) \
         else (lambda *a: None)
 
