@@ -180,7 +180,8 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         info = ctx.pk_info(prover.pk_h)
-        kname = "msm_accumulate_shared<Fq>" if info["g1_shared"] else "msm_accumulate<Fq, false>"
+        kname = ("msm_accumulate_comb<Fq, false>" if info["g1_comb_k"] else
+                 "msm_accumulate_shared<Fq>" if info["g1_shared"] else "msm_accumulate<Fq, false>")
         roofline = {"bound": "hbm", "kernel": f"{kname} (G1 MSMs of the key)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
@@ -190,7 +191,10 @@ def main():
         # v_mad_u64_u32 view beside the HBM one.  1548 mads per mixed addition (csrc/ec29.h), one
         # addition per (base, window, proof); peak 3.55e13 lane-mads/s measured by
         # tools/instr_rate.hip (profiles/r01_instr_rate.log).
-        madds = sum(ns) * info["g1_windows"] * B
+        if info["g1_comb_k"]:      # one addition per (group of k bases, bit, proof)
+            madds = sum(-(-n // info["g1_comb_k"]) for n in ns) * info["g1_windows"] * B
+        else:
+            madds = sum(ns) * info["g1_windows"] * B
         roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1548 / msm_s,
                            "peak": 3.55e13, "frac": madds * 1548 / msm_s / 3.55e13}
         try:

@@ -405,7 +405,10 @@ static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size
   for (;;) {
     int rc = msm_bases_build(ctx, group, bases_dev, n, plan, out);
     if (rc != ZKMI_ERR_OOM || !may_relax) return rc;
-    if (plan.shared) {
+    if (plan.comb) {
+      if (plan.comb <= 8) return rc;
+      plan = plan_comb(plan.comb - 1);
+    } else if (plan.shared) {
       if (plan.bits[0] <= 4) return rc;
       plan = plan_shared(plan.bits[0] - 1);
     } else {
@@ -417,10 +420,22 @@ static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size
 
 // explicit window_bits of the C-ABI: 2..16 = per-window tables, uniform width; 100 + c = one
 // shared table of c-bit signed digits per base (c in 4..16)
+// 200 + k = comb tables over groups of k bases (k in 2..20)
 static bool window_bits_ok(int wb) {
-  return wb == 0 || (wb >= 2 && wb <= 16) || (wb >= 104 && wb <= 116);
+  return wb == 0 || (wb >= 2 && wb <= 16) || (wb >= 104 && wb <= 116) || (wb >= 202 && wb <= 220);
 }
-static WinPlan plan_explicit(int wb) { return wb >= 100 ? plan_shared(wb - 100) : plan_uniform(wb); }
+static WinPlan plan_explicit(int wb) {
+  return wb >= 200 ? plan_comb(wb - 200) : wb >= 100 ? plan_shared(wb - 100) : plan_uniform(wb);
+}
+// auto plans: comb tables unless ZKMI_MSM_COMB=0
+static bool comb_default() {
+  static const bool v = [] {
+    const char* e = getenv("ZKMI_MSM_COMB");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+static const int COMB_WINDOWS = 254;
 // auto plans: shared tables unless ZKMI_MSM_SHARED=0 asks for the per-window layout
 static bool shared_default() {
   static const bool v = [] {
@@ -449,7 +464,7 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
   ZK_HIP(hipSetDevice(ctx->device));
   if (!out) return ZKMI_ERR_ARG;
   if (!window_bits_ok(window_bits)) {
-    ctx->err = "window_bits must be 0 (auto), in [2,16] or 100 + [4,16]";
+    ctx->err = "window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
     return ZKMI_ERR_ARG;
   }
   Staged sb(ctx);
@@ -468,6 +483,13 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
                              &c1, &c2);
       const WinPlan ps = plan_shared(group == 1 ? c1 : c2);
       if (ps.W < plan.W) plan = ps;
+    }
+    if (comb_default() && n >= 64) {
+      int k1, k2;
+      plan_comb_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(),
+                           &k1, &k2);
+      const int k = group == 1 ? k1 : k2;
+      if ((double)COMB_WINDOWS / k < (double)plan.W) plan = plan_comb(k);
     }
   }
   return bases_load_plan(ctx, group, sb.dev, n, plan, window_bits == 0, out);
@@ -611,7 +633,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   // one window plan per group for the whole key, sized against free HBM
   const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
   if (!window_bits_ok((int)d->window_bits_g1) || !window_bits_ok((int)d->window_bits_g2)) {
-    ctx->err = "pk: window_bits must be 0 (auto), in [2,16] or 100 + [4,16]";
+    ctx->err = "pk: window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
     delete pk;
     return ZKMI_ERR_ARG;
   }
@@ -626,6 +648,15 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
                      : plan_explicit((int)d->window_bits_g2);
   if (auto1 && sc1 && plan_shared(sc1).W < p1.W) p1 = plan_shared(sc1);
   if (auto2 && sc2 && plan_shared(sc2).W < p2.W) p2 = plan_shared(sc2);
+  // comb tables (joint tables over k bases) when they need fewer additions per base still; small
+  // keys keep the layouts above (their MSMs are latency, not throughput)
+  if (comb_default() && n1 >= 4096) {
+    int k1 = 0, k2 = 0;
+    plan_comb_for_budget(auto1 ? n1 : 0, auto2 ? d->n_b : 0,
+                         usable_table_bytes() - (auto1 ? 0.0 : 0.0), &k1, &k2);
+    if (auto1 && (double)COMB_WINDOWS / k1 < (double)p1.W) p1 = plan_comb(k1);
+    if (auto2 && (double)COMB_WINDOWS / k2 < (double)p2.W) p2 = plan_comb(k2);
+  }
   auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
                   zkmi_msm_bases** out) -> int {
     Staged sb(ctx);
@@ -672,6 +703,8 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info) {
   info[5] = pk->B2->table_bytes;
   info[6] = pk->Z->plan.shared;
   info[7] = pk->B2->plan.shared;
+  info[8] = pk->Z->plan.comb;
+  info[9] = pk->B2->plan.comb;
   return ZKMI_OK;
 }
 
@@ -868,7 +901,7 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
         (rc = ensure_scratch(ctx, si == 0 ? 15 : 14, Bp * (7 * 128 + 2 * 256 + 256), &dummy)))
       return rc;
   }
-  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15, Bp * (7 * 128 + 2 * 256 + 256 + 64 * (4 * 128 + 256)),
+  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15, Bp * (7 * 128 + 2 * 256 + 256 + 256 * (4 * 128 + 256)),
                            &S.sums)))
     return rc;
   S.heavy_enqueued = false;
@@ -919,7 +952,7 @@ struct SumsView {
   G1XYZZ *sA, *sB1, *sK, *sZ, *tR, *tS, *tNRS;
   G2XYZZ *sB2, *tS2;
   ProofOut* proofs;
-  G1XYZZ* w1[4];   // deferred window sums of A, B1, K, Z ([<= 64][Bp] each), shared-table plans
+  G1XYZZ* w1[4];   // deferred window sums of A, B1, K, Z ([<= 256][Bp] each)
   G2XYZZ* w2;
   SumsView(void* base, size_t Bp) {
     char* m = (char*)base;
@@ -935,7 +968,7 @@ struct SumsView {
     proofs = (ProofOut*)m;  m += Bp * 256;
     for (int i = 0; i < 4; i++) {
       w1[i] = (G1XYZZ*)m;
-      m += 64 * Bp * 128;
+      m += 256 * Bp * 128;
     }
     w2 = (G2XYZZ*)m;
   }
@@ -967,7 +1000,8 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   S.msm_ev_used = 0;
   ctx->msm_ev_set = si;
   // shared-table plans: stop at the window sums, the Horner step runs with the assembly
-  const bool d1 = pk->Z->plan.shared, d2 = pk->B2->plan.shared;
+  const bool d1 = pk->Z->plan.shared || pk->Z->plan.comb;
+  const bool d2 = pk->B2->plan.shared || pk->B2->plan.comb;
   if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true, d1 ? v.w1[0] : nullptr)) ||
       (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true, d1 ? v.w1[1] : nullptr)) ||
       (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true, d1 ? v.w1[2] : nullptr)) ||
@@ -1011,12 +1045,14 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
   hipStream_t q3 = ctx->stream3;
   ZK_HIP(hipStreamWaitEvent(q3, S.evq[4], 0));
   hipEventRecord(S.eva[0], q3);
-  if (pk->Z->plan.shared) {
+  if (pk->Z->plan.shared || pk->Z->plan.comb) {
     void* ws[4] = {v.w1[0], v.w1[1], v.w1[2], v.w1[3]};
     void* os[4] = {v.sA, v.sB1, v.sK, v.sZ};
     const zkmi_msm_bases* ms[4] = {pk->A, pk->B1, pk->K, pk->Z};
     bool same = true;   // an out-of-memory relaxation may have narrowed one table
-    for (int i = 0; i < 3; i++) same = same && ms[i]->plan.bits[0] == pk->Z->plan.bits[0];
+    for (int i = 0; i < 3; i++)
+      same = same && ms[i]->plan.bits[0] == pk->Z->plan.bits[0] &&
+             ms[i]->plan.comb == pk->Z->plan.comb;
     if (same) {
       if ((rc = msm_horner_run(ctx, q3, 1, pk->Z->plan, 4, ws, os, Bp))) return rc;
     } else {
@@ -1024,7 +1060,7 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
         if ((rc = msm_horner_run(ctx, q3, 1, ms[i]->plan, 1, ws + i, os + i, Bp))) return rc;
     }
   }
-  if (pk->B2->plan.shared) {
+  if (pk->B2->plan.shared || pk->B2->plan.comb) {
     void* ws[1] = {v.w2};
     void* os[1] = {v.sB2};
     if ((rc = msm_horner_run(ctx, q3, 2, pk->B2->plan, 1, ws, os, Bp))) return rc;

@@ -272,6 +272,177 @@ __global__ __launch_bounds__(64) void msm_horner(HornerArgs<F> args, size_t Bp, 
   out[b] = acc;
 }
 
+// ---- comb tables: one mixed addition per (group of k bases, bit, proof) ------------------------------
+// A table over single bases spends 2^(c-1) entries per base to consume c scalar bits per addition.
+// A JOINT table over k bases with one-bit digits, T[g][m] = sum_{i in m} P_{gk+i} for every non-empty
+// subset m, spends 2^k / k entries per base and consumes k scalar bits per addition: k = 18 fits
+// the HBM that gave c = 15 (14.1 instead of 17 additions per base and proof), and the G2 table
+// affords k = 19.  Digits are plain bits -- no signs, no recoding: the index of (group, bit j) is
+// bit j of the group's k scalars, 0 = nothing to add.  The 254 window sums go through the same
+// chunk reduction and a Horner pass of one doubling per window.
+constexpr int COMB_W = 254;   // scalars are below 2^254
+
+// D[g][t] = P_t - (P_0 + ... + P_{t-1}): entry(m + 1) = entry(m) + D[number of trailing ones of m]
+template <class F>
+__global__ void comb_prep(const Affine<F>* __restrict__ bases, uint32_t n, uint32_t k,
+                          uint32_t n_groups, Affine<F>* __restrict__ dpts) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  XYZZ<F> s = XYZZ<F>::inf();
+  for (uint32_t t = 0; t < k; t++) {
+    const size_t i = (size_t)g * k + t;
+    const Affine<F> P = i < n ? bases[i] : Affine<F>::inf();
+    XYZZ<F> d = s;
+    d.y = neg(d.y);
+    madd(d, P);
+    dpts[i] = to_affine(d);
+    madd(s, P);
+  }
+}
+
+// one thread per (group, segment of seg_len consecutive subset masks)
+template <class F>
+__global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ bases,
+                                                 const Affine<F>* __restrict__ dpts, uint32_t n,
+                                                 uint32_t k, uint64_t r0, uint64_t n_rows,
+                                                 Affine<F>* __restrict__ table,
+                                                 F* __restrict__ scratch, uint32_t T,
+                                                 uint32_t seg_len, int* __restrict__ any_inf) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = r0 + t;
+  if (t >= T || r >= n_rows) return;
+  const uint32_t per_group = 1u << k, segs = per_group / seg_len;
+  const uint32_t g = (uint32_t)(r / segs), m0 = (uint32_t)(r % segs) * seg_len;
+  F* szz = scratch + t;
+  F* szzz = scratch + (size_t)seg_len * T + t;
+  F* spre = scratch + (size_t)2 * seg_len * T + t;
+  Affine<F>* seg = table + (size_t)g * per_group + m0;
+  // subset sum of the first mask of the segment
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t i = 0; i < k; i++)
+    if ((m0 >> i) & 1u) {
+      const size_t bi = (size_t)g * k + i;
+      if (bi < n) madd(acc, bases[bi]);
+    }
+  F pref = F::one();
+  bool inf_seen = false;
+  for (uint32_t d = 0; d < seg_len; d++) {
+    const bool is_inf = acc.is_inf();
+    inf_seen = inf_seen || (is_inf && (m0 + d) != 0);
+    seg[d].x = is_inf ? F::zero() : acc.x;
+    seg[d].y = is_inf ? F::zero() : acc.y;
+    szz[(size_t)d * T] = is_inf ? F::one() : acc.zz;
+    szzz[(size_t)d * T] = is_inf ? F::one() : acc.zzz;
+    spre[(size_t)d * T] = pref;
+    pref = mul(pref, is_inf ? F::one() : acc.zzz);
+    const uint32_t tz = (uint32_t)__builtin_ctz(m0 + d + 1);   // trailing ones of the mask
+    if (tz < k) madd(acc, dpts[(size_t)g * k + tz]);
+  }
+  F inv = inverse(pref);
+  for (uint32_t d = seg_len; d-- > 0;) {
+    const F zzz = szzz[(size_t)d * T];
+    const F izzz = mul(inv, spre[(size_t)d * T]);
+    inv = mul(inv, zzz);
+    const F izz = sqr(mul(izzz, szz[(size_t)d * T]));
+    // entries are stored in the 2^261 domain of the accumulate kernels (0 stays 0)
+    seg[d].x = to_r261_domain(mul(seg[d].x, izz));
+    seg[d].y = to_r261_domain(mul(seg[d].y, izzz));
+  }
+  if (inf_seen) atomicOr(any_inf, 1);
+}
+
+// Montgomery scalars -> plain integers, same planar layout (row i of the output = base i)
+__global__ __launch_bounds__(256) void comb_scalars_kernel(const Fr* __restrict__ scalars,
+                                                           const uint32_t* __restrict__ row_idx,
+                                                           size_t Bp, uint32_t n, int32_t kmul32,
+                                                           const uint8_t* __restrict__ inf,
+                                                           Fr* __restrict__ out) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    Fr s = Fr::zero();
+    if (!inf[i]) {   // the point at infinity contributes nothing: its bits never enter an index
+      Fr29 kk = Fr29::zero();
+      kk.v[0] = kmul32;
+      const Fr raw = bi_ld(scalars, row_idx ? row_idx[i] : i, b, Bp);
+      pack_canonical<Fr29Params>(s.v, mul(unpack29<Fr29Params>(raw.v), kk));
+    }
+    bi_st(out, i, b, Bp, s);
+  }
+}
+
+// digits[j][g][b] = sum_i bit_j(s[gk+i][b]) << i
+template <int KMAX>
+__global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__ sint, size_t Bp,
+                                                          uint32_t n, uint32_t k, uint32_t n_groups,
+                                                          uint32_t* __restrict__ digits) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4* base = reinterpret_cast<const uint4*>(sint);
+  for (uint32_t g = blockIdx.y; g < n_groups; g += gridDim.y) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint4 wv[KMAX];
+#pragma unroll
+      for (int i = 0; i < KMAX; i++) {
+        const size_t bi = (size_t)g * k + i;
+        wv[i] = (i < (int)k && bi < n) ? base[(bi * 2 + h) * Bp + b] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        for (int bit = 0; bit < 32; bit++) {
+          const int j = (h * 4 + c) * 32 + bit;
+          if (j >= COMB_W) break;
+          uint32_t idx = 0;
+#pragma unroll
+          for (int i = 0; i < KMAX; i++) {
+            const uint32_t word = c == 0 ? wv[i].x : c == 1 ? wv[i].y : c == 2 ? wv[i].z : wv[i].w;
+            idx |= ((word >> bit) & 1u) << i;
+          }
+          digits[((size_t)j * n_groups + g) * Bp + b] = idx;
+        }
+      }
+    }
+  }
+}
+
+// grid: x over proofs, y over the 254 bits, z over chunks of groups
+template <class F, bool CHECK_INF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void
+msm_accumulate_comb(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ digits,
+                    size_t Bp, uint32_t n_groups, uint32_t per_chunk, uint32_t per_group,
+                    XYZZ<F>* __restrict__ partial) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t chunk = blockIdx.z, j = blockIdx.y;
+  const uint32_t g0 = chunk * per_chunk;
+  uint32_t g1 = g0 + per_chunk;
+  if (g1 > n_groups) g1 = n_groups;
+  const uint32_t* dj = digits + (size_t)j * n_groups * Bp + b;
+  typename Acc29<F>::type acc = Acc29<F>::type::infinity();
+  for (uint32_t g = g0; g < g1; g++) {
+    const uint32_t m = dj[(size_t)g * Bp];
+    if (m) {
+      const Affine<F> e = table[(size_t)g * per_group + m];
+      if (CHECK_INF && e.is_inf()) continue;
+      Acc29<F>::add(acc, e, false);
+    }
+  }
+  partial[((size_t)j * gridDim.z + chunk) * Bp + b] = to_std(acc);
+}
+
+// out[b] = sum_j 2^j * wsum[j][b], j < W
+template <class F>
+__global__ __launch_bounds__(64) void msm_horner_comb(HornerArgs<F> args, size_t Bp, int W) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  const XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
+  XYZZ<F> acc = wsum[(size_t)(W - 1) * Bp + b];
+  for (int j = W - 2; j >= 0; j--) {
+    acc = dbl(acc);
+    const XYZZ<F> p = wsum[(size_t)j * Bp + b];
+    padd(acc, p);
+  }
+  args.out[blockIdx.y][b] = acc;
+}
+
 // sums groups of `group` consecutive chunk partials: out[g][b] = sum_{k < group} in[g*group + k][b]
 // (blockIdx.z selects an independent set: partial += z * in_zstride, out += z * out_zstride)
 template <class F>
@@ -344,6 +515,33 @@ WinPlan plan_shared(int c) {   // ceil(255 / c) windows over ONE table of 2^(c-1
   p.per_base = 1u << (c - 1);
   return p;
 }
+WinPlan plan_comb(int k) {
+  WinPlan p;
+  if (k < 2) k = 2;
+  if (k > 20) k = 20;
+  p.comb = (uint8_t)k;
+  p.W = COMB_W;
+  p.per_base = 0;
+  return p;
+}
+// Group sizes of the comb tables of a key: the (k1, k2) minimising n1 / k1 + 3 * n2 / k2 among those
+// whose tables (2^k entries per group) fit `usable_bytes`.
+void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2) {
+  double best = 1e300;
+  *k1 = *k2 = 8;
+  for (int a = 8; a <= 20; a++)
+    for (int b = 8; b <= 20; b++) {
+      const double g1 = (double)((n1 + a - 1) / a), g2 = (double)((n2 + b - 1) / b);
+      const double bytes = g1 * (double)(1u << a) * 64.0 + g2 * (double)(1u << b) * 128.0;
+      if (bytes > usable_bytes) continue;
+      const double cost = g1 + 3.0 * g2;
+      if (cost < best) {
+        best = cost;
+        *k1 = a;
+        *k2 = b;
+      }
+    }
+}
 // Widths of the shared tables of a key: the (c1, c2) that minimises n1 * W(c1) + 3 * n2 * W(c2)
 // (a G2 mixed addition costs about three G1 ones) among those whose tables fit `usable_bytes`.
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2) {
@@ -390,6 +588,39 @@ __global__ void msm_inf_flags(const Affine<F>* __restrict__ bases, uint32_t n,
 }
 
 template <class F>
+static int build_comb(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
+                      Affine<F>* table, int* any_inf_host) {
+  const uint32_t k = plan.comb;
+  const size_t n_groups = (n + k - 1) / k;
+  const uint32_t per_group = 1u << k;
+  const uint32_t seg_len = per_group < 512u ? per_group : 512u;
+  const uint64_t n_rows = (uint64_t)n_groups * (per_group / seg_len);
+  const size_t per_thread = (size_t)3 * seg_len * sizeof(F);
+  size_t T = (size_t)2e9 / per_thread;
+  if (T > n_rows) T = (size_t)n_rows;
+  T = round_up(T, 64);
+  if (T > 262144) T = 262144;
+  void* scratch;
+  const size_t dp_bytes = round_up(n_groups * k * sizeof(Affine<F>), 256);
+  int rc = ensure_scratch(ctx, 7, dp_bytes + 256 + per_thread * T, &scratch);
+  if (rc) return rc;
+  Affine<F>* dpts = (Affine<F>*)scratch;
+  int* any_inf = (int*)((char*)scratch + dp_bytes);
+  F* inv_scratch = (F*)((char*)scratch + dp_bytes + 256);
+  ZK_HIP(hipMemsetAsync(any_inf, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL((comb_prep<F>), dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0,
+                     ctx->stream, bases_dev, (uint32_t)n, k, (uint32_t)n_groups, dpts);
+  for (uint64_t r0 = 0; r0 < n_rows; r0 += T)
+    hipLaunchKernelGGL((comb_build<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
+                       bases_dev, (const Affine<F>*)dpts, (uint32_t)n, k, r0, n_rows, table,
+                       inv_scratch, (uint32_t)T, seg_len, any_inf);
+  ZK_HIP(hipGetLastError());
+  ZK_HIP(hipMemcpyAsync(any_inf_host, any_inf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+template <class F>
 static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
   const uint32_t Dmax = plan.shared ? plan.per_base : 1u << (plan.bits[0] - 1);
@@ -424,7 +655,9 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
   b->n = n;
   b->plan = plan;
   const size_t entry = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
-  b->table_bytes = n * (size_t)plan.per_base * entry;
+  b->n_groups = plan.comb ? (n + plan.comb - 1) / plan.comb : 0;
+  b->table_bytes = plan.comb ? b->n_groups * ((size_t)1 << plan.comb) * entry
+                             : n * (size_t)plan.per_base * entry;
   if (n == 0) {
     *out = b;
     return ZKMI_OK;
@@ -449,9 +682,16 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
   else
     hipLaunchKernelGGL((msm_inf_flags<Fq2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, (const G2Affine*)bases_dev, (uint32_t)n, b->inf);
-  int rc = group == 1
-               ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table)
-               : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan, (G2Affine*)b->table);
+  int rc;
+  if (plan.comb)
+    rc = group == 1 ? build_comb<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table,
+                                     &b->entries_may_be_inf)
+                    : build_comb<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan,
+                                      (G2Affine*)b->table, &b->entries_may_be_inf);
+  else
+    rc = group == 1
+             ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table)
+             : build_impl<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan, (G2Affine*)b->table);
   if (rc) {
     hipFree(b->table);
     hipFree(b->inf);
@@ -474,6 +714,72 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     kmul = from_mont(inverse(to_mont(t)));
   }
   const size_t n = bases->n;
+  if (bases->plan.comb) {
+    const uint32_t k = bases->plan.comb;
+    const size_t G = bases->n_groups;
+    const int W = COMB_W;
+    size_t chunks = (size_t)8 * 262144 / Bp / (size_t)W;
+    if (chunks < 1) chunks = 1;
+    if (chunks > G) chunks = G;
+    const uint32_t per_chunk = (uint32_t)((G + chunks - 1) / chunks);
+    chunks = (G + per_chunk - 1) / per_chunk;
+    uint32_t group = 1;
+    while ((size_t)group * group < chunks) group++;
+    const uint32_t ngroups = (uint32_t)((chunks + group - 1) / group);
+    void *partial, *digits, *sint;
+    int rc = ensure_scratch(ctx, 6, ((chunks + ngroups + 1) * W) * Bp * sizeof(XYZZ<F>), &partial);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(ctx, 12, (size_t)W * G * Bp * sizeof(uint32_t), &digits))) return rc;
+    if ((rc = ensure_scratch(ctx, 17, n * Bp * sizeof(Fr), &sint))) return rc;
+    XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
+    XYZZ<F>* wsum = wsum_out ? wsum_out : mid + (size_t)ngroups * W * Bp;
+    const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
+    hipLaunchKernelGGL(comb_scalars_kernel,
+                       dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
+                       ctx->stream, scalars, row_idx, Bp, (uint32_t)n,
+                       (int32_t)(scalars_f ? 1 : 32), (const uint8_t*)bases->inf, (Fr*)sint);
+    hipLaunchKernelGGL((comb_digits_kernel<20>),
+                       dim3((unsigned)(Bp / bx), (unsigned)(G < 8192 ? G : 8192)), dim3(bx), 0,
+                       ctx->stream, (const Fr*)sint, Bp, (uint32_t)n, k, (uint32_t)G,
+                       (uint32_t*)digits);
+    zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
+    const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
+    if (ev >= 0) {
+      es->msm_ev_group[ev] = bases->group;
+      hipEventRecord(es->msm_ev[ev][0], ctx->stream);
+    }
+    const dim3 grid((unsigned)(Bp / bx), (unsigned)W, (unsigned)chunks);
+    if (bases->entries_may_be_inf)
+      hipLaunchKernelGGL((msm_accumulate_comb<F, true>), grid, dim3(bx), 0, ctx->stream,
+                         (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G,
+                         per_chunk, 1u << k, (XYZZ<F>*)partial);
+    else
+      hipLaunchKernelGGL((msm_accumulate_comb<F, false>), grid, dim3(bx), 0, ctx->stream,
+                         (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G,
+                         per_chunk, 1u << k, (XYZZ<F>*)partial);
+    if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
+    if (ngroups > 1) {
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), ngroups, (unsigned)W), dim3(64),
+                         0, ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid,
+                         chunks * Bp, (size_t)ngroups * Bp);
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
+                         ctx->stream, (const XYZZ<F>*)mid, Bp, ngroups, ngroups, wsum,
+                         (size_t)ngroups * Bp, Bp);
+    } else {
+      hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
+                         ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks,
+                         (uint32_t)chunks, wsum, chunks * Bp, Bp);
+    }
+    if (!wsum_out) {
+      HornerArgs<F> ha{};
+      ha.wsum[0] = wsum;
+      ha.out[0] = out;
+      hipLaunchKernelGGL((msm_horner_comb<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0,
+                         ctx->stream, ha, Bp, W);
+    }
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+  }
   if (bases->plan.shared) {
     const WinPlan& plan = bases->plan;
     const int W = plan.W;
@@ -630,16 +936,24 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& 
       ha.wsum[i] = (const G1XYZZ*)wsums[i];
       ha.out[i] = (G1XYZZ*)outs[i];
     }
-    hipLaunchKernelGGL((msm_horner<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
-                       stream, ha, Bp, plan);
+    if (plan.comb)
+      hipLaunchKernelGGL((msm_horner_comb<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count),
+                         dim3(64), 0, stream, ha, Bp, plan.W);
+    else
+      hipLaunchKernelGGL((msm_horner<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
+                         stream, ha, Bp, plan);
   } else {
     HornerArgs<Fq2> ha{};
     for (int i = 0; i < count; i++) {
       ha.wsum[i] = (const G2XYZZ*)wsums[i];
       ha.out[i] = (G2XYZZ*)outs[i];
     }
-    hipLaunchKernelGGL((msm_horner<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
-                       stream, ha, Bp, plan);
+    if (plan.comb)
+      hipLaunchKernelGGL((msm_horner_comb<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count),
+                         dim3(64), 0, stream, ha, Bp, plan.W);
+    else
+      hipLaunchKernelGGL((msm_horner<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64),
+                         0, stream, ha, Bp, plan);
   }
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
@@ -647,7 +961,7 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& 
 
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
             size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out) {
-  if (bases->n == 0 && wsum_out && bases->plan.shared) {
+  if (bases->n == 0 && wsum_out && (bases->plan.shared || bases->plan.comb)) {
     // deferred path: every window sum is the identity
     const size_t cnt = (size_t)bases->plan.W * Bp;
     if (bases->group == 1)

@@ -54,7 +54,7 @@ struct zkmi_ctx {
   hipEvent_t ev[8] = {};
   double timings[8] = {};
   // scratch arena for the prove pipeline, grown on demand
-  zk::DevBuf scratch[16];
+  zk::DevBuf scratch[20];
   // software pipeline over batches: the latency-bound witness solve of batch k+1 runs on
   // `stream2` (16 wavefronts at batch 1024) underneath the NTT/MSM kernels of batch k.
   // `stream3` runs the 16-wavefront assembly of batch k underneath the quotient kernels of batch k+1.
@@ -91,6 +91,10 @@ struct WinPlan {
   // shared = 1: ONE table d * P_i, d = 1..2^(c-1), serves every window (off[j] = 0); the windows
   // are accumulated separately and combined with Horner's rule at the end (msm.hip)
   uint8_t shared = 0;
+  // comb = k > 0: joint table over groups of k consecutive bases, T[g][m] = sum_{i in m} P_{gk+i}
+  // for every non-empty subset m (2^k entries, entry 0 unused), 254 one-bit windows: 254 / k mixed
+  // additions per (base, proof).  W = 254; bits/off are not used.
+  uint8_t comb = 0;
 };
 
 struct zkmi_msm_bases {
@@ -100,6 +104,8 @@ struct zkmi_msm_bases {
   void* table = nullptr;  // affine entries [(i * W + j) << (c-1) | (d-1)]
   size_t table_bytes = 0;
   uint8_t* inf = nullptr;  // device, n flags: base i is the point at infinity (skipped)
+  size_t n_groups = 0;     // comb plans: ceil(n / k)
+  int entries_may_be_inf = 0;  // comb plans: some subset of a group sums to the identity
 };
 
 struct zkmi_pk {
@@ -195,6 +201,8 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 // maps base i to its scalar row.  out_xyzz: Bp accumulators.
 // scalars_f: the scalars are in the F domain (solver output) instead of gnark's image
 WinPlan plan_shared(int c);
+WinPlan plan_comb(int k);
+void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2);
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
             size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr);

@@ -183,11 +183,11 @@ class Context:
         return h
 
     def pk_info(self, h):
-        arr = (C.c_uint64 * 8)()
+        arr = (C.c_uint64 * 10)()
         self._check(self.lib.zkmi_pk_info(h, arr), "zkmi_pk_info")
         return dict(zip(("g1_windows", "g1_entries_per_base", "g2_windows", "g2_entries_per_base",
-                         "g1_table_bytes", "g2_table_bytes", "g1_shared", "g2_shared"),
-                        [int(x) for x in arr]))
+                         "g1_table_bytes", "g2_table_bytes", "g1_shared", "g2_shared",
+                         "g1_comb_k", "g2_comb_k"), [int(x) for x in arr]))
 
     def pk_free(self, h):
         self.lib.zkmi_pk_free(self.h, h)

@@ -73,7 +73,10 @@ int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, voi
  *   window_bits = 0: widest windows the free HBM allows, ONE table d*P (d = 1..2^(c-1)) per base
  *                    shared by all windows, per-window accumulators combined by Horner's rule;
  *   100 + c (c in 4..16): that layout with an explicit width;
- *   c in 2..16: the per-window layout (a table d*2^(c*j)*P for every window j, one accumulator). */
+ *   c in 2..16: the per-window layout (a table d*2^(c*j)*P for every window j, one accumulator);
+ *   200 + k (k in 2..20): comb tables -- one joint table of all subset sums per group of k bases,
+ *                    254 one-bit windows (254 / k additions per base and proof).  Auto picks the
+ *                    layout with the fewest additions that fits. */
 typedef struct zkmi_msm_bases zkmi_msm_bases;
 int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
                         zkmi_msm_bases** out);
@@ -117,8 +120,9 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* desc, zkmi_pk** out);
 void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk);
 /* Window plan chosen for the key: info[0] = windows per G1 scalar, [1] = table entries per G1
  * base, [2] = windows per G2 scalar, [3] = table entries per G2 base, [4] = G1 table bytes (all
- * four MSMs), [5] = G2 table bytes, [6] / [7] = 1 when the G1 / G2 tables are shared-table plans. */
-int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 8 */);
+ * four MSMs), [5] = G2 table bytes, [6] / [7] = 1 when the G1 / G2 tables are shared-table plans,
+ * [8] / [9] = group size k of the G1 / G2 comb tables (0 otherwise; then [0] / [2] = 254). */
+int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
 
 /* -- constraint system (witness program) ----------------------------------------------------- */
 /* What cs.R1CS.Solve needs, in the straight-line form produced by

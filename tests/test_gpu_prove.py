@@ -106,7 +106,8 @@ def test_invalid_witness_status(zk_ctx, poseidon_setup):
 
 
 @pytest.mark.parametrize("levels,populated,wbits", [(8, 3, (7, 5)), (24, 0, (7, 5)),
-                                                    (8, 5, (109, 106)), (12, 2, (0, 0))])
+                                                    (8, 5, (109, 106)), (12, 2, (0, 0)),
+                                                    (8, 4, (210, 207))])
 def test_smt_inclusion_prove(zk_ctx, levels, populated, wbits):
     from oracle import cref
     cc = compile_circuit(circuits.smt_inclusion_circuit(levels))
@@ -298,7 +299,7 @@ def test_prove_empty_and_single(zk_ctx, poseidon_setup):
     assert np.array_equal(one[0], many[1])
 
 
-@pytest.mark.parametrize("wbits", [(7, 5), (105, 104), (0, 0)])
+@pytest.mark.parametrize("wbits", [(7, 5), (105, 104), (0, 0), (204, 203)])
 def test_degenerate_circuits(zk_ctx, wbits):
     """Smallest possible keys: one linear constraint between public inputs (no private wire at all:
     the K MSM is empty), and one product with a single internal wire (domain 2^1 / 2^0 edge)."""
