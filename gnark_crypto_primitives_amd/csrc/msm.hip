@@ -317,18 +317,23 @@ __global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ b
   F* szzz = scratch + (size_t)seg_len * T + t;
   F* spre = scratch + (size_t)2 * seg_len * T + t;
   Affine<F>* seg = table + (size_t)g * per_group + m0;
-  // subset sum of the first mask of the segment
+  // subset sum of the first mask of the segment; `live` = bases that exist and are finite (the
+  // digit pass never sets the bit of any other base, so masks outside `live` are never gathered)
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t i = 0; i < k; i++)
-    if ((m0 >> i) & 1u) {
-      const size_t bi = (size_t)g * k + i;
-      if (bi < n) madd(acc, bases[bi]);
-    }
+  uint32_t live = 0;
+  for (uint32_t i = 0; i < k; i++) {
+    const size_t bi = (size_t)g * k + i;
+    if (bi >= n) continue;
+    const Affine<F> P = bases[bi];
+    if (!P.is_inf()) live |= 1u << i;
+    if ((m0 >> i) & 1u) madd(acc, P);
+  }
   F pref = F::one();
   bool inf_seen = false;
   for (uint32_t d = 0; d < seg_len; d++) {
     const bool is_inf = acc.is_inf();
-    inf_seen = inf_seen || (is_inf && (m0 + d) != 0);
+    const uint32_t m = m0 + d;
+    inf_seen = inf_seen || (is_inf && m != 0 && (m & ~live) == 0);
     seg[d].x = is_inf ? F::zero() : acc.x;
     seg[d].y = is_inf ? F::zero() : acc.y;
     szz[(size_t)d * T] = is_inf ? F::one() : acc.zz;
@@ -428,19 +433,54 @@ msm_accumulate_comb(const Affine<F>* __restrict__ table, const uint32_t* __restr
   partial[((size_t)j * gridDim.z + chunk) * Bp + b] = to_std(acc);
 }
 
-// out[b] = sum_j 2^j * wsum[j][b], j < W
+// out[b] = sum_j 2^j * wsum[j][b], j < W, in two levels so that the dependent chain is short:
+// comb_fold8 replaces wsum[8q] by sum_{i<8} 2^i wsum[8q+i] (one lane per (proof, q), 7 doublings +
+// 7 additions), msm_horner_comb then runs Horner over the folded sums (8 doublings + 1 addition per
+// step): 256 doublings + 32 additions on the critical path instead of 254 + 254.
 template <class F>
-__global__ __launch_bounds__(64) void msm_horner_comb(HornerArgs<F> args, size_t Bp, int W) {
+struct HornerArgsRW {
+  XYZZ<F>* wsum[4];
+  XYZZ<F>* out[4];
+};
+template <class F>
+__global__ __launch_bounds__(64) void comb_fold8(HornerArgsRW<F> args, size_t Bp, int W) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
-  const XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
-  XYZZ<F> acc = wsum[(size_t)(W - 1) * Bp + b];
-  for (int j = W - 2; j >= 0; j--) {
+  XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
+  const int j0 = 8 * (int)blockIdx.z;
+  int top = j0 + 7;
+  if (top > W - 1) top = W - 1;
+  XYZZ<F> acc = wsum[(size_t)top * Bp + b];
+  for (int j = top - 1; j >= j0; j--) {
     acc = dbl(acc);
     const XYZZ<F> p = wsum[(size_t)j * Bp + b];
     padd(acc, p);
   }
+  wsum[(size_t)j0 * Bp + b] = acc;
+}
+template <class F>
+__global__ __launch_bounds__(64) void msm_horner_comb(HornerArgsRW<F> args, size_t Bp, int W) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bp) return;
+  const XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
+  const int Q = (W + 7) / 8;
+  XYZZ<F> acc = wsum[(size_t)(8 * (Q - 1)) * Bp + b];
+  for (int q = Q - 2; q >= 0; q--) {
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) acc = dbl(acc);
+    const XYZZ<F> p = wsum[(size_t)(8 * q) * Bp + b];
+    padd(acc, p);
+  }
   args.out[blockIdx.y][b] = acc;
+}
+template <class F>
+static void launch_comb_horner(hipStream_t stream, const HornerArgsRW<F>& ha, int count, size_t Bp,
+                               int W) {
+  hipLaunchKernelGGL((comb_fold8<F>),
+                     dim3((unsigned)(Bp / 64), (unsigned)count, (unsigned)((W + 7) / 8)), dim3(64), 0,
+                     stream, ha, Bp, W);
+  hipLaunchKernelGGL((msm_horner_comb<F>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
+                     stream, ha, Bp, W);
 }
 
 // sums groups of `group` consecutive chunk partials: out[g][b] = sum_{k < group} in[g*group + k][b]
@@ -771,11 +811,10 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
                          (uint32_t)chunks, wsum, chunks * Bp, Bp);
     }
     if (!wsum_out) {
-      HornerArgs<F> ha{};
+      HornerArgsRW<F> ha{};
       ha.wsum[0] = wsum;
       ha.out[0] = out;
-      hipLaunchKernelGGL((msm_horner_comb<F>), dim3((unsigned)(Bp / 64), 1), dim3(64), 0,
-                         ctx->stream, ha, Bp, W);
+      launch_comb_horner<F>(ctx->stream, ha, 1, Bp, W);
     }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
@@ -936,10 +975,14 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& 
       ha.wsum[i] = (const G1XYZZ*)wsums[i];
       ha.out[i] = (G1XYZZ*)outs[i];
     }
-    if (plan.comb)
-      hipLaunchKernelGGL((msm_horner_comb<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count),
-                         dim3(64), 0, stream, ha, Bp, plan.W);
-    else
+    if (plan.comb) {
+      HornerArgsRW<Fq> hw{};
+      for (int i = 0; i < count; i++) {
+        hw.wsum[i] = (G1XYZZ*)wsums[i];
+        hw.out[i] = (G1XYZZ*)outs[i];
+      }
+      launch_comb_horner<Fq>(stream, hw, count, Bp, plan.W);
+    } else
       hipLaunchKernelGGL((msm_horner<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
                          stream, ha, Bp, plan);
   } else {
@@ -948,10 +991,14 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& 
       ha.wsum[i] = (const G2XYZZ*)wsums[i];
       ha.out[i] = (G2XYZZ*)outs[i];
     }
-    if (plan.comb)
-      hipLaunchKernelGGL((msm_horner_comb<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count),
-                         dim3(64), 0, stream, ha, Bp, plan.W);
-    else
+    if (plan.comb) {
+      HornerArgsRW<Fq2> hw{};
+      for (int i = 0; i < count; i++) {
+        hw.wsum[i] = (G2XYZZ*)wsums[i];
+        hw.out[i] = (G2XYZZ*)outs[i];
+      }
+      launch_comb_horner<Fq2>(stream, hw, count, Bp, plan.W);
+    } else
       hipLaunchKernelGGL((msm_horner<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64),
                          0, stream, ha, Bp, plan);
   }
