@@ -188,15 +188,16 @@ def main():
                     "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
                     "algorithmic_bytes_per_launch": alg_bytes / 4.0}
         # The kernel is bound by the integer multiplier, not HBM: report the
-        # v_mad_u64_u32 view beside the HBM one.  1548 mads per mixed addition (csrc/ec29.h), one
+        # v_mad_u64_u32 view beside the HBM one.  1467 mads per mixed addition (csrc/ec29.h: 6 products x 162, 2 squares x 126, one
+        # two-product sum with a shared reduction 243), one
         # addition per (base, window, proof); peak 3.55e13 lane-mads/s measured by
         # tools/instr_rate.hip (profiles/r01_instr_rate.log).
         if info["g1_comb_k"]:      # one addition per (group of k bases, bit, proof)
             madds = sum(-(-n // info["g1_comb_k"]) for n in ns) * info["g1_windows"] * B
         else:
             madds = sum(ns) * info["g1_windows"] * B
-        roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1548 / msm_s,
-                           "peak": 3.55e13, "frac": madds * 1548 / msm_s / 3.55e13}
+        roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1467 / msm_s,
+                           "peak": 3.55e13, "frac": madds * 1467 / msm_s / 3.55e13}
         try:
             roofline["alu"]["fq_mul_per_s_ff29_microbench"] = ctx.field_mul_bench(2, 1 << 22, 256)
         except Exception:
