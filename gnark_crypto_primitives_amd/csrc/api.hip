@@ -20,7 +20,9 @@ int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out) {
     }
     hipError_t e = hipMalloc(&s.p, bytes);
     if (e != hipSuccess) {
-      ctx->err = "hipMalloc(" + std::to_string(bytes) + " B) failed: " + hipGetErrorString(e);
+      ctx->err = "hipMalloc(" + std::to_string(bytes) + " B) failed: " + hipGetErrorString(e) +
+                 " (working set of this batch does not fit beside the MSM tables: load the key with"
+                 " a larger ZKMI_TABLE_RESERVE_GB, default 32)";
       s.p = nullptr;
       return ZKMI_ERR_OOM;
     }
