@@ -758,7 +758,12 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     const uint32_t k = bases->plan.comb;
     const size_t G = bases->n_groups;
     const int W = COMB_W;
-    size_t chunks = (size_t)8 * 262144 / Bp / (size_t)W;
+    static const size_t comb_factor = [] {
+      const char* e = getenv("ZKMI_MSM_CHUNKS");
+      const long v = e ? atol(e) : 16;   // measured 4 / 8 / 12 / 16 / 24: 277 / 275 / 273.5 / 272 / 273.6 ms
+      return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    size_t chunks = comb_factor * 262144 / Bp / (size_t)W;
     if (chunks < 1) chunks = 1;
     if (chunks > G) chunks = G;
     const uint32_t per_chunk = (uint32_t)((G + chunks - 1) / chunks);
