@@ -14,6 +14,7 @@ int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out) {
   if (s.bytes < bytes) {
     if (s.p) {
       hipStreamSynchronize(ctx->stream);
+      if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
       hipFree(s.p);
       s.p = nullptr;
       s.bytes = 0;
@@ -236,6 +237,8 @@ int zkmi_init(int device, zkmi_ctx** out) {
     }
   }
   for (auto& e : ctx->ev) hipEventCreate(&e);
+  for (auto& e : ctx->part_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  for (auto& e : ctx->acc_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
   ctx->plans.reserve(32);
   *out = ctx;
   return ZKMI_OK;
@@ -274,6 +277,10 @@ void zkmi_destroy(zkmi_ctx* ctx) {
   for (auto& s : ctx->scratch)
     if (s.p) hipFree(s.p);
   for (auto& e : ctx->ev)
+    if (e) hipEventDestroy(e);
+  for (auto& e : ctx->part_ev)
+    if (e) hipEventDestroy(e);
+  for (auto& e : ctx->acc_ev)
     if (e) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1004,15 +1011,16 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   // shared-table plans: stop at the window sums, the Horner step runs with the assembly
   const bool d1 = pk->Z->plan.shared || pk->Z->plan.comb;
   const bool d2 = pk->B2->plan.shared || pk->B2->plan.comb;
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true, d1 ? v.w1[0] : nullptr)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true, d1 ? v.w1[1] : nullptr)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true, d1 ? v.w1[2] : nullptr)) ||
-      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr))) {
+  hipStream_t q3 = ctx->stream3;
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true, d1 ? v.w1[0] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true, d1 ? v.w1[1] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true, d1 ? v.w1[2] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr, q3))) {
     ctx->msm_ev_set = -1;
     return rc;
   }
   hipEventRecord(S.evq[2], ctx->stream);
-  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true, d2 ? v.w2 : nullptr);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true, d2 ? v.w2 : nullptr, q3);
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);
@@ -1079,7 +1087,9 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
   // look ahead: queue the next batch's heavy kernels before blocking on this batch's assembly
   zkmi_ctx::ProveSet& N = ctx->sets[si ^ 1];
   if (N.pending && !N.heavy_enqueued && (rc = enqueue_heavy(ctx, si ^ 1))) return rc;
-  ZK_HIP(hipStreamSynchronize(q3));
+  // wait for THIS batch's copies only: the look-ahead has queued the next batch's MSM tails behind
+  // them on the same stream
+  ZK_HIP(hipEventSynchronize(S.eva[1]));
   S.pending = false;
   S.heavy_enqueued = false;
   ctx->next_collect ^= 1;

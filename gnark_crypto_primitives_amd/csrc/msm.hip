@@ -745,7 +745,7 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 template <class F>
 static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
                     const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f,
-                    XYZZ<F>* wsum_out) {
+                    XYZZ<F>* wsum_out, hipStream_t finish_stream) {
   Fr kmul = Fr::zero();
   kmul.v[0] = 1;  // plain 1: from_mont
   if (scalars_f) {  // plain 2^-5 mod r
@@ -772,8 +772,17 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     while ((size_t)group * group < chunks) group++;
     const uint32_t ngroups = (uint32_t)((chunks + group - 1) / group);
     void *partial, *digits, *sint;
-    int rc = ensure_scratch(ctx, 6, ((chunks + ngroups + 1) * W) * Bp * sizeof(XYZZ<F>), &partial);
+    // deferred tail: the reductions run on finish_stream while the next MSM's accumulate already
+    // writes the other partial buffer
+    const bool defer = wsum_out && finish_stream && finish_stream != ctx->stream;
+    const int pb = defer ? (int)(ctx->part_next++ & 1u) : 0;
+    int rc = ensure_scratch(ctx, pb ? 16 : 6,
+                            ((chunks + ngroups + 1) * W) * Bp * sizeof(XYZZ<F>), &partial);
     if (rc) return rc;
+    if (ctx->part_ev_valid[pb]) {   // the last reduction that read this buffer must be done
+      ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[pb], 0));
+      ctx->part_ev_valid[pb] = false;
+    }
     if ((rc = ensure_scratch(ctx, 12, (size_t)W * G * Bp * sizeof(uint32_t), &digits))) return rc;
     if ((rc = ensure_scratch(ctx, 17, n * Bp * sizeof(Fr), &sint))) return rc;
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
@@ -803,17 +812,27 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
                          (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G,
                          per_chunk, 1u << k, (XYZZ<F>*)partial);
     if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
+    hipStream_t rq = ctx->stream;
+    if (defer) {
+      ZK_HIP(hipEventRecord(ctx->acc_ev[pb], ctx->stream));
+      ZK_HIP(hipStreamWaitEvent(finish_stream, ctx->acc_ev[pb], 0));
+      rq = finish_stream;
+    }
     if (ngroups > 1) {
       hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), ngroups, (unsigned)W), dim3(64),
-                         0, ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid,
+                         0, rq, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, group, mid,
                          chunks * Bp, (size_t)ngroups * Bp);
       hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
-                         ctx->stream, (const XYZZ<F>*)mid, Bp, ngroups, ngroups, wsum,
+                         rq, (const XYZZ<F>*)mid, Bp, ngroups, ngroups, wsum,
                          (size_t)ngroups * Bp, Bp);
     } else {
       hipLaunchKernelGGL((msm_reduce<F>), dim3((unsigned)(Bp / 64), 1, (unsigned)W), dim3(64), 0,
-                         ctx->stream, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks,
-                         (uint32_t)chunks, wsum, chunks * Bp, Bp);
+                         rq, (const XYZZ<F>*)partial, Bp, (uint32_t)chunks, (uint32_t)chunks, wsum,
+                         chunks * Bp, Bp);
+    }
+    if (defer) {
+      ZK_HIP(hipEventRecord(ctx->part_ev[pb], finish_stream));
+      ctx->part_ev_valid[pb] = true;
     }
     if (!wsum_out) {
       HornerArgsRW<F> ha{};
@@ -853,6 +872,10 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     void *partial, *digits;
     int rc = ensure_scratch(ctx, 6, ((chunks + ngroups + 1) * W) * Bp * sizeof(XYZZ<F>), &partial);
     if (rc) return rc;
+    if (ctx->part_ev_valid[0]) {   // a deferred comb tail may still be reading this buffer
+      ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[0], 0));
+      ctx->part_ev_valid[0] = false;
+    }
     if ((rc = ensure_scratch(ctx, 12, (size_t)W * n * Bp * sizeof(int16_t), &digits))) return rc;
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
     // window sums: into the caller's buffer when the Horner step is deferred (msm_horner_run)
@@ -919,6 +942,10 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   // partials + room for the intermediate level of the reduction
   int rc = ensure_scratch(ctx, 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
+  if (ctx->part_ev_valid[0]) {   // a deferred tail of an earlier MSM may still be reading this buffer
+    ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[0], 0));
+    ctx->part_ev_valid[0] = false;
+  }
   static const unsigned bx_cfg = [] {
     const char* e = getenv("ZKMI_MSM_BLOCK");
     const long v = e ? atol(e) : 256;
@@ -1012,7 +1039,7 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& 
 }
 
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out) {
+            size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out, hipStream_t finish_stream) {
   if (bases->n == 0 && wsum_out && (bases->plan.shared || bases->plan.comb)) {
     // deferred path: every window sum is the identity
     const size_t cnt = (size_t)bases->plan.W * Bp;
@@ -1037,9 +1064,9 @@ int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const
   }
   if (bases->group == 1)
     return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz, scalars_f,
-                        (G1XYZZ*)wsum_out);
+                        (G1XYZZ*)wsum_out, finish_stream);
   return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz, scalars_f,
-                       (G2XYZZ*)wsum_out);
+                       (G2XYZZ*)wsum_out, finish_stream);
 }
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n) {

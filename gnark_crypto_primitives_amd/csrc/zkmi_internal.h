@@ -77,6 +77,12 @@ struct zkmi_ctx {
   int next_submit = 0, next_collect = 0;
   // set whose proving-key MSM launches are currently being bracketed with HIP events (or null)
   int msm_ev_set = -1;
+  // deferred MSM tails (msm_run with a finish stream): the chunk partials of consecutive MSMs
+  // alternate between two buffers; part_ev[k] = last reduction that read buffer k has finished
+  // (recorded on the finish stream), acc_ev[k] = last accumulate that wrote it (main stream)
+  hipEvent_t part_ev[2] = {}, acc_ev[2] = {};
+  bool part_ev_valid[2] = {false, false};
+  unsigned part_next = 0;
 };
 
 // Window plan of a fixed-base table: W windows whose sizes sum to exactly 255 bits (scalars are
@@ -205,10 +211,14 @@ WinPlan plan_comb(int k);
 void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2);
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr);
+            size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr,
+            hipStream_t finish_stream = nullptr);
 // With wsum_out (shared-table plans only) msm_run stops at the W window sums ([W][Bp] XYZZ) and the
 // caller finishes with msm_horner_run -- 255 dependent doublings per proof, latency-bound, which
-// the prover runs on its assembly stream under the next batch's kernels.
+// the prover runs on its assembly stream under the next batch's kernels.  With finish_stream the
+// sums over the chunk partials run there too (ordered after the accumulate launch by an event; the
+// partials of consecutive MSMs alternate between two buffers), so the main stream holds nothing
+// but the digit pass and the accumulate kernel.
 int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& plan, int count,
                    void* const* wsums, void* const* outs, size_t Bp);
 
