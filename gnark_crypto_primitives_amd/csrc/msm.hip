@@ -5,21 +5,24 @@
 // [UPSTREAM-RECALL, SURVEY.md §3.2 step 5].  The result is the affine group element, which is
 // canonical, so it equals gnark's bucket-method result bit for bit.
 //
-// MI355X-first design (DESIGN.md §MSM).  gnark runs Pippenger per proof because a CPU sees one
+// MI355X-first design (DESIGN.md §3.2).  gnark runs Pippenger per proof because a CPU sees one
 // proof at a time.  Here a batch of proofs shares the bases, and the bases are fixed for the
-// lifetime of the circuit, so the work is organised the other way round:
-//   * pk_load expands every base into an HBM-resident table of all signed window multiples
-//     T[i][j][d-1] = d * 2^(c*j) * P_i, d = 1..2^(c-1), affine.  With c = 10 that is ~0.85 MB
-//     per G1 base - ~140 GB for the 166 k G1 bases of the Arbo-160 circuit - which is exactly what
-//     288 GB of HBM3E is for.  There are no buckets, no bucket reduction, no sorting.
-//   * one lane = one proof.  A wavefront walks a contiguous chunk of (base, window) pairs; at
-//     each step all 64 lanes need an entry of the SAME 2^(c-1)-entry table slice, selected by
-//     their own digit, and add it into a register-resident XYZZ accumulator with one mixed
-//     addition.  Scalars are read once, coalesced across lanes; the table slice is shared by
-//     every wave working on that chunk, so it streams from HBM once per batch.
-//   * a second tiny kernel sums the per-chunk partial accumulators of each proof.
-// Cost: ceil(255/c) mixed additions per (base, proof) and nothing else.  The bound is the vector
-// integer ALU (v_mad_u64_u32), not HBM; both fractions are reported by bench.py.
+// lifetime of the circuit, so the work is organised the other way round: multiples of the bases are
+// precomputed in HBM, one lane = one proof, and every step is ONE mixed addition of a gathered
+// table entry into a register-resident XYZZ accumulator -- no buckets, no bucket reduction, no
+// sorting, no atomics.  Three table layouts, chosen per key by the additions they need within
+// the HBM budget:
+//   * comb tables (default for keys of >= 4096 bases): a joint table of all subset sums of every
+//     group of k consecutive bases, 254 one-bit windows: 254 / k additions per (base, proof)
+//     (k = 18 / 19 for the Arbo-160 key).  Window index = a grid dimension; the 254 window sums of
+//     a proof are combined by Horner's rule.
+//   * one shared table per base (d * P, d = 1..2^(c-1)), ceil(255 / c) signed-digit windows with
+//     their own accumulators, Horner combine (explicit window_bits 100 + c).
+//   * per-window tables (d * 2^(shift_j) * P for every window j), all windows into one
+//     accumulator: no Horner tail, the right shape for small keys and for the one-base delta
+//     multiples of the assembly.
+// The bound is the vector integer ALU (v_mad_u64_u32), not HBM; both fractions are reported by
+// bench.py.
 //
 // Algorithmic bytes per launch: n * sizeof(affine) + batch * n * 32.
 #include <cstdlib>
