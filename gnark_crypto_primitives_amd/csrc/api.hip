@@ -13,7 +13,9 @@ int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out) {
   DevBuf& s = ctx->scratch[slot];
   if (s.bytes < bytes) {
     if (s.p) {
+      // nothing queued on any of the context's streams may still use the old buffer
       hipStreamSynchronize(ctx->stream);
+      if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
       if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
       hipFree(s.p);
       s.p = nullptr;
@@ -899,7 +901,11 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
   int rc;
   const int base = si == 0 ? 0 : 8;   // scratch slots 0-3,5 (set 0) / 8-11,13 (set 1)
   void* misc;
-  {  // size the other set too, so steady-state submits never allocate
+  // Size the other set too, so that steady-state submits never allocate -- but only while that
+  // set is idle: a pending set keeps raw pointers into its buffers (S.slots, S.a, ...), and its
+  // solve / quotient / MSM kernels may be running on them.  A pending set is resized by its own
+  // next submit, after its collect.
+  if (!ctx->sets[si ^ 1].pending) {
     void* dummy;
     const int ob = si == 0 ? 8 : 0;
     if ((rc = ensure_scratch(ctx, ob + 0, (size_t)cs->n_slots * Bp * 32, &dummy)) ||

@@ -30,6 +30,7 @@ OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SE
     OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC = range(17)
 
 HINT_INVZERO, HINT_NBITS = 1, 2
+FIELD_BITS = 254      # bit length of r
 
 
 class Variable:
@@ -397,8 +398,10 @@ class API:
         return res
 
     # ------------------------------------------------------------------ bits
-    def ToBinary(self, a, n=254):
-        """std/math/bits.ToBinary with WithNbDigits(n): LSB first."""
+    def ToBinary(self, a, n=254, omit_modulus_check=False):
+        """std/math/bits.ToBinary with WithNbDigits(n): LSB first.  With n = the field's bit
+        length gnark also asserts that the bits are <= r - 1 (``omitReducednessCheck`` is false
+        unless n < FieldBitLen or OmitModulusCheck() is passed) [UPSTREAM-RECALL]."""
         a = self._v(a)
         if a.is_const():
             v = a.const_value()
@@ -417,7 +420,47 @@ class API:
             self.AssertIsBoolean(b)
             acc = self.Add(acc, self._mul2(b, pow(2, i, R)))
         self.AssertIsEqual(acc, a)
+        if n >= FIELD_BITS and not omit_modulus_check:
+            # reducedness: without it any s < 2^254 - r also decomposes as the bits of s + r
+            self._must_be_less_or_eq_cst(bits, R - 1)
         return bits
+
+    def _must_be_less_or_eq_cst(self, bits, bound):
+        """gnark r1cs builder ``MustBeLessOrEqCst(aBits, bound)`` [UPSTREAM-RECALL]: with
+        p[i] = AND of a[j] for the one-bits j >= i of the bound ("a equals the bound down to bit
+        i"), a zero-bit of the bound forces a[i] = 0 while the prefix is still equal:
+        (1 - p[i+1] - a[i]) * a[i] == 0.  One product per one-bit above the bound's trailing ones,
+        one row per zero-bit."""
+        nb = len(bits)
+        if bound >> nb:
+            return                      # every nb-bit value is below the bound
+        t = 0
+        while t < nb and (bound >> t) & 1:
+            t += 1
+        p = [None] * (nb + 1)
+        p[nb] = self._const(1)
+        for i in range(nb - 1, t - 1, -1):
+            p[i] = self._mul2(p[i + 1], bits[i]) if (bound >> i) & 1 else p[i + 1]
+        for i in range(nb - 1, -1, -1):
+            if (bound >> i) & 1:
+                self.AssertIsBoolean(bits[i])
+            else:
+                self._add_r1c(self.Sub(1, p[i + 1], bits[i]), bits[i], self._zero())
+                self._mark_boolean(bits[i])
+
+    def AssertIsLessOrEqual(self, v, bound):
+        """frontend.API.AssertIsLessOrEqual for a constant bound (the only form the gadgets and
+        std/math/bits use): binary decomposition of v, then MustBeLessOrEqCst."""
+        b = self._v(bound)
+        if not b.is_const():
+            raise CompileError("AssertIsLessOrEqual: only constant bounds are supported")
+        v = self._v(v)
+        if v.is_const():
+            if v.const_value() > b.const_value():
+                raise CompileError("constant exceeds the bound")
+            return
+        bits = self.ToBinary(v, FIELD_BITS, omit_modulus_check=True)
+        self._must_be_less_or_eq_cst(bits, b.const_value())
 
     def FromBinary(self, *bits):
         acc = self._const(0)

@@ -118,3 +118,62 @@ def test_wire_order_and_layout():
     assert cc.n_public == 2 and cc.n_secret == 2
     assert cc.program.shape[1] == 4 and cc.program[-1, 0] == 0
     assert cc.n_slots >= cc.n_wires
+
+
+def test_to_binary_254_rejects_the_unreduced_decomposition():
+    """ADVICE r1 / gnark std/math/bits ToBinary with NbDigits == FieldBitLen [UPSTREAM-RECALL]:
+    besides booleanity and recomposition the bits must be <= r - 1.  For s < 2^254 - r the bits of
+    s + r recompose to s mod r as well; that assignment satisfies every other row and must fail."""
+    from gnark_crypto_primitives_amd.frontend import Public
+
+    class Bits:
+        X = Public()
+        B0 = Public()
+
+        def define(self, api):
+            bits = api.ToBinary(self.X, 254)
+            api.AssertIsEqual(bits[0], self.B0)
+
+    cc = compile_circuit(Bits())
+    # 254 booleanity rows + recomposition + equality + MustBeLessOrEqCst(r - 1)
+    ones = bin(R - 1).count("1")
+    assert cc.n_constraints == 254 + 1 + 1 + (ones - 1) + (254 - ones)
+    s = 12345
+    wires, *_ = cc.run_program(cc.assignment_vector({"X": s, "B0": s & 1}))
+    assert cc.last_status == 0 and cc.is_satisfied(wires)[0]
+    # forge: replace the bit wires by the bits of s + r (still 254 bits) and re-derive the
+    # products p[i] the comparison allocates, so that only the zero-bit rows can object
+    assert (s + R) >> 254 == 0
+    alias = [((s + R) >> i) & 1 for i in range(254)]
+    bit_wires = list(range(cc.n_public, cc.n_public + 254))
+    forged = list(wires)
+    for w, b in zip(bit_wires, alias):
+        forged[w] = b
+    p = 1
+    nxt = cc.n_public + 254
+    first = True
+    for i in range(253, -1, -1):
+        if ((R - 1) >> i) & 1:
+            p = p * alias[i]
+            if first:
+                first = False          # p[253] = 1 * a[253]: no wire
+            else:
+                forged[nxt] = p
+                nxt += 1
+    assert nxt == cc.n_wires
+    forged[2] = alias[0]               # public B0 follows the forged bit 0
+    ok, row = cc.is_satisfied(forged)
+    assert not ok
+    L, Rr, O, *_ = cc.constraints[row]
+    assert not O                        # the failing row is a (1 - p - a) * a == 0 comparison row
+    # AssertIsLessOrEqual against a small constant
+    class Le:
+        X = Public()
+
+        def define(self, api):
+            api.AssertIsLessOrEqual(self.X, 1000)
+
+    cc = compile_circuit(Le())
+    for x, good in ((0, True), (1000, True), (1001, False), (R - 1, False)):
+        cc.run_program(cc.assignment_vector({"X": x}))
+        assert (cc.last_status == 0) == good, x
