@@ -6,8 +6,11 @@
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 One step = one pass of the whole prove path (witness solve -> quotient (6 NTTs) -> 4 G1 + 1 G2 MSM ->
-assembly) over one batch of synthetic witnesses that is already resident in HBM.  Ranks are
-independent (weak scaling: every rank proves its own batch; no data-path collective).
+assembly) over one batch of synthetic witnesses that is already resident in HBM, ending with the
+RCCL all_gather of the 264-byte proof records (the only exchange the path has).  Default scaling is
+weak (every rank proves its own batch of --batch proofs, the headline configuration);
+--scaling strong splits ONE global batch of --batch proofs across the ranks (BASELINE configs 3 and
+4: --workload verifier --batch 4096, --workload elgamal-add --batch 8192).
 """
 import argparse
 import json
@@ -41,6 +44,41 @@ def available_cpus():
     return min(n, 16)
 
 
+def _gen_chunk(job):
+    workload, levels, populated, seed, count = job
+    from gnark_crypto_primitives_amd import workloads
+    from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+    _, gen, _ = workloads.build(workload, levels, populated)
+    rng = random.Random(seed)
+    return [to_mont_array(_GEN_CC.assignment_vector(gen(rng))) for _ in range(count)]
+
+
+_GEN_CC = None
+
+
+def generate_witnesses(cc, workload, levels, jobs, workers):
+    """jobs: [(name, seed, count, populated)] -> {name: [input arrays]}.  Chunks of 32 witnesses
+    are dealt to a fork()ed process pool (off-circuit Poseidon in Python big ints is ~0.3 ms per
+    hash: 1024 fully populated 160-level paths are 50 s on one core)."""
+    global _GEN_CC
+    _GEN_CC = cc
+    chunks, owner = [], []
+    for name, seed, count, populated in jobs:
+        for c0 in range(0, count, 32):
+            chunks.append((workload, levels, populated, seed * 100003 + c0, min(32, count - c0)))
+            owner.append(name)
+    out = {name: [] for name, *_ in jobs}
+    if workers <= 1 or len(chunks) <= 1:
+        res = [_gen_chunk(c) for c in chunks]
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(chunks))) as pool:
+            res = pool.map(_gen_chunk, chunks)
+    for name, r in zip(owner, res):
+        out[name].extend(r)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,107 +101,186 @@ def main():
                     help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=-1,
                     help="rehearsal only: put every rank on this device instead of LOCAL_RANK")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch proofs per GPU; strong: --batch proofs in all, sharded")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: still create the (one-rank) process group and run the "
+                         "per-step all_gather -- rehearsal of the N > 1 path on a one-GPU box")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="skip the per-step all_gather of proof records (N > 1)")
+    ap.add_argument("--worst-case-steps", type=int, default=-1,
+                    help="arbo only: extra timed steps on witnesses with every level populated "
+                         "(every wire differs between lanes); -1: steps / 4, 0: skip")
+    ap.add_argument("--gen-workers", type=int, default=0, help="witness generator processes")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one blocking zkmi_prove_batch per step (no overlap of consecutive steps)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from gnark_crypto_primitives_amd import backend, groth16, lib, workloads
+    from gnark_crypto_primitives_amd import backend, workloads
     from gnark_crypto_primitives_amd.frontend import compile_circuit
     from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
 
     rank, world, local_rank = backend.env_rank_world()
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) \
+        else (lambda *a: None)
+    t0 = time.time()
+    circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
+    cc = compile_circuit(circuit)
+    log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops "
+        f"({time.time() - t0:.1f}s)")
+
+    # ---- synthetic witnesses, seeded per rank, generated by worker processes
+    # BEFORE this process touches the GPU (nothing is forked once HIP is initialised)
+    if args.scaling == "strong":
+        g_lo, g_hi = backend.shard_range(args.batch, rank, world)
+        B, global_batch = g_hi - g_lo, args.batch
+    else:
+        B, global_batch = args.batch, args.batch * world
+    n_distinct = min(B, args.distinct) if args.distinct > 0 else B
+    wc_steps = args.worst_case_steps if args.worst_case_steps >= 0 else max(args.steps // 4, 2)
+    if args.workload != "arbo" or args.populated >= args.levels - 1:
+        wc_steps = 0
+    jobs = [("main", 1000 + rank, n_distinct, args.populated)]
+    if wc_steps:
+        jobs.append(("worst", 5000 + rank, B, args.levels - 1))
+    sets = generate_witnesses(cc, args.workload, args.levels, jobs, args.gen_workers or
+                              max(1, available_cpus() // max(1, min(world, 8))))
+    ws = sets["main"]
+    inp_h = np.stack([ws[i % n_distinct] for i in range(B)]) if B else \
+        np.zeros((0, cc.n_inputs, 4), np.uint64)
+    rng = random.Random(1000 + rank)
+    rs_h = np.stack([to_mont_array([rng.randrange(workloads.R), rng.randrange(workloads.R)])
+                     for _ in range(max(B, 1))])[:B]
+    log(f"witnesses generated ({time.time() - t0:.1f}s)")
+
+    import torch
+    import torch.distributed as dist
+    from gnark_crypto_primitives_amd import groth16, lib
+
     if args.device >= 0:
         local_rank = args.device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # collectives' tensors
-    if world > 1:
+    pg = world > 1 or args.force_collective
+    if pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.dist_backend)
-    if world > 1:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if pg:
         # first collective now: RCCL's buffers are allocated before the MSM tables size themselves
         # against the free HBM
         t = torch.zeros(1, dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         if cdev.type == "cuda":
             torch.cuda.synchronize()
-    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) \
-        else (lambda *a: None)
 
-    t0 = time.time()
     ctx = lib.Context(local_rank)
-    circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
-    cc = compile_circuit(circuit)
-    log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops "
-        f"({time.time() - t0:.1f}s)")
     pk, vk, _ = groth16.setup(cc, 2, groth16.gpu_mul(ctx))
     log(f"setup: log_n={pk.log_n} A={len(pk.a_wire)} B={len(pk.b_wire)} K={len(pk.k_wire)} "
         f"Z={pk.g1_z.shape[0]} ({time.time() - t0:.1f}s)")
-    prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2)
+    prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2, max_batch=max(B, 64))
     log(f"key resident, window tables built ({time.time() - t0:.1f}s)")
 
-    # synthetic witnesses, seeded per rank
-    rng = random.Random(1000 + rank)
-    B = args.batch
-    n_distinct = min(B, args.distinct) if args.distinct > 0 else B
-    ws = [to_mont_array(cc.assignment_vector(gen(rng))) for _ in range(n_distinct)]
-    inp_h = np.stack([ws[i % n_distinct] for i in range(B)])
-    rs_h = np.stack([to_mont_array([rng.randrange(workloads.R), rng.randrange(workloads.R)])
-                     for _ in range(B)])
-    inp_d = torch.from_numpy(inp_h.view(np.int64)).to(dev)
-    rs_d = torch.from_numpy(rs_h.view(np.int64)).to(dev)
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    inp_d, rs_d = to_dev(inp_h), to_dev(rs_h)
     proofs_d = torch.zeros((B, 32), dtype=torch.int64, device=dev)
     status_d = torch.zeros(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     log(f"witnesses resident ({time.time() - t0:.1f}s)")
+    gather = pg and not args.no_gather
+    gathered = [None]
+
+    def finish_step():
+        """the path's only exchange: all_gather of this step's proof records (RCCL on device
+        tensors; gloo rehearsals stage through the host)"""
+        if not gather:
+            return
+        if cdev.type == "cuda":
+            gathered[0] = backend.gather_proofs(proofs_d, status_d, global_batch, force=True)
+        else:
+            gathered[0] = backend.gather_proofs(proofs_d.cpu().numpy().view(np.uint64),
+                                                status_d.cpu().numpy(), global_batch, "cpu",
+                                                force=True)
+
+    def timed_steps(steps, inp, rsd):
+        """K steps bracketed by barrier + synchronize on both sides; returns (max-over-ranks
+        seconds, per-stage ms summed over the steps)."""
+        stage = np.zeros(8)
+        if pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        if B == 0:
+            for _ in range(steps):
+                finish_step()
+        elif args.no_pipeline:
+            for _ in range(steps):
+                prover.prove(inp, rsd, proofs_d, status_d)
+                stage += np.array(ctx.last_timings())
+                finish_step()
+        else:
+            prover.submit(inp, rsd)
+            for k in range(steps):
+                if k + 1 < steps:
+                    prover.submit(inp, rsd)
+                prover.collect(proofs_d, status_d)
+                stage += np.array(ctx.last_timings())
+                finish_step()
+        torch.cuda.synchronize()
+        if pg:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        if pg:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, stage
 
     # Steps are software-pipelined two deep through the library's submit/collect pair: the
     # latency-bound witness solve of step k+1 (16 wavefronts) runs on a second HIP stream under the
     # NTT/MSM kernels of step k.  The timed region contains K submits and K collects: the first
     # solve is exposed, nothing of the timed work happens outside the region.
     for _ in range(args.warmup):
-        prover.prove(inp_d, rs_d, proofs_d, status_d)
-    stage = np.zeros(8)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    if args.no_pipeline:
-        for _ in range(args.steps):
+        if B:
             prover.prove(inp_d, rs_d, proofs_d, status_d)
-            stage += np.array(ctx.last_timings())
-    else:
-        prover.submit(inp_d, rs_d)
-        for k in range(args.steps):
-            if k + 1 < args.steps:
-                prover.submit(inp_d, rs_d)
-            prover.collect(proofs_d, status_d)
-            stage += np.array(ctx.last_timings())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        finish_step()
+    elapsed, stage = timed_steps(args.steps, inp_d, rs_d)
     status = status_d.cpu().numpy()
     n_bad = int((status != 0).sum())
-    if world > 1:
+    if pg:
         t = torch.tensor([n_bad], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         n_bad = int(t.item())
     proofs = proofs_d.cpu().numpy().view(np.uint64)
-
+    gather_ok = None
+    if gather:
+        gp, gs = gathered[0]
+        gp = gp.cpu().numpy().view(np.uint64) if hasattr(gp, "cpu") else gp
+        lo = backend.shard_range(global_batch, rank, world)[0] if args.scaling == "strong" \
+            else rank * B
+        gather_ok = bool(gp.shape == (global_batch, 32) and np.array_equal(gp[lo:lo + B], proofs)
+                         and int((np.asarray(gs.cpu() if hasattr(gs, "cpu") else gs) != 0).sum())
+                         == n_bad)
+    # worst case for the table gathers: every level populated, so every wire differs between lanes
+    worst = None
+    if wc_steps:
+        inp_w = to_dev(np.stack(sets["worst"]))
+        prover.prove(inp_w, rs_d, proofs_d, status_d)
+        e_w, st_w = timed_steps(wc_steps, inp_w, rs_d)
+        bad_w = int((status_d.cpu().numpy() != 0).sum())
+        worst = {"value": global_batch * wc_steps / e_w, "steps": wc_steps,
+                 "populated": args.levels - 1, "ms_per_step": e_w / wc_steps * 1e3,
+                 "msm_g1_kernel_only_ms": st_w[6] / wc_steps, "unsatisfied": bad_w}
     if rank == 0:
         stage /= max(args.steps, 1)
         # ---- roofline of the dominant kernel: the G1 accumulate kernel, four launches per step
-        # (msm_accumulate_shared<Fq> under the default shared-table plan; stage[6] = sum of the HIP
+        # (msm_accumulate_comb<Fq, false> under the default comb plan; stage[6] = sum of the HIP
         # event pairs that bracket each accumulate launch alone)
         ns = [len(pk.a_wire), len(pk.b_wire), len(pk.k_wire), pk.g1_z.shape[0]]
         alg_bytes = sum(n * 64 + B * n * 32 for n in ns)          # SURVEY.md §8d
@@ -171,20 +288,24 @@ def main():
         achieved = alg_bytes / msm_s / 1e9 if msm_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE +
         # WRITE_SIZE of the four launches, raw counter values; same circuit, batch and windows)
-        traffic = None
+        info = ctx.pk_info(prover.pk_h)
+        traffic, traffic_source = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             if pm.get("batch") == B and pm.get("levels") == args.levels and \
-                    args.workload == "arbo":
+                    args.workload == "arbo" and pm.get("g1_comb_k") == info["g1_comb_k"] and \
+                    pm.get("populated") == args.populated:
                 traffic = pm["msm_g1_bytes_per_launch"]
+                traffic_source = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of tools/pmc_collect.sh over this build and "
+                                  "plan; not collected inside this run)")
         except (OSError, ValueError, KeyError):
             pass
-        info = ctx.pk_info(prover.pk_h)
         kname = ("msm_accumulate_comb<Fq, false>" if info["g1_comb_k"] else
                  "msm_accumulate_shared<Fq>" if info["g1_shared"] else "msm_accumulate<Fq, false>")
         roofline = {"bound": "hbm", "kernel": f"{kname} (G1 MSMs of the key)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                     "launches_per_step": 4, "avg_launch_ms": stage[6] / 4.0,
                     "algorithmic_bytes_per_launch": alg_bytes / 4.0}
         # The kernel is bound by the integer multiplier, not HBM: report the
@@ -220,17 +341,27 @@ def main():
             "metric": "proofs/sec, Arbo-160 Poseidon SMT-verifier circuit, Groth16/BN254"
                       if args.workload == "arbo" and args.levels == 160
                       else f"proofs/sec, {label}, Groth16/BN254",
-            "value": world * B * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
+            "value": global_batch * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)",
             "data": "synthetic",
-            "config": {"workload": f"{label}, batch {B} proofs per GPU",
+            "config": {"workload": f"{label}, batch {B} proofs per GPU"
+                                   + (f" (global batch {global_batch} sharded)"
+                                      if args.scaling == "strong" else ""),
                        "constraints": cc.n_constraints, "wires": cc.n_wires,
                        "domain_log2": pk.log_n, "batch_per_gpu": B,
                        "msm_terms_per_proof": {"g1": int(sum(ns)), "g2": ns[1]},
                        "msm_window_tables": ctx.pk_info(prover.pk_h),
-                       "parallelism": f"batch-split x{world}, no collective"},
+                       "global_batch": global_batch,
+                       "parallelism": (f"batch-split x{world} ({args.scaling} scaling), "
+                                       f"{args.dist_backend if pg else 'no'} process group "
+                                       f"of {world} rank(s)"
+                                       + (", all_gather of 264-B proof records per step"
+                                          if gather else ", no collective in the data path"))},
+            "gathered_on_every_rank": gather_ok,
+            "value_worst_case": worst["value"] if worst else None,
+            "worst_case": worst,
             "pipelined": not args.no_pipeline,
             "stage_ms": {"solve": stage[0], "quotient_ntt": stage[1], "msm_g1": stage[2],
                          "msm_g2": stage[3], "assemble_overlapped": stage[4], "main_stream_span": stage[5],
@@ -242,7 +373,7 @@ def main():
         print(json.dumps(out))
     prover.close()
     ctx.close()
-    if world > 1:
+    if pg:
         dist.destroy_process_group()
 
 

@@ -24,31 +24,48 @@ def env_rank_world():
         int(os.environ.get("LOCAL_RANK", 0))
 
 
-def gather_proofs(local_proofs: np.ndarray, local_status: np.ndarray, batch: int, device=None):
+def gather_proofs(local_proofs, local_status, batch: int, device=None, force: bool = False):
     """all_gather of each rank's shard -> full [batch, 32] proofs and [batch] status on every rank.
-    Shards may differ by one proof; they are padded to the largest shard for the collective."""
+    Shards may differ by one proof; they are padded to the largest shard for the collective.
+
+    numpy in -> numpy out (staged through ``device``: "cpu" for gloo, a cuda device for RCCL);
+    torch tensors in (int64 [n, 32] proofs, int32 [n] status, e.g. the buffers zkmi_prove_collect
+    wrote on the GPU) -> torch tensors out on the same device, no host round trip.
+    ``force``: run the collective even in a one-rank group (self-tests of the RCCL path)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local_proofs, local_status
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world = dist.get_world_size()
     cap = -(-batch // world)
-    dev = device if device is not None else "cpu"
+    as_tensor = isinstance(local_proofs, torch.Tensor)
+    if as_tensor:
+        dev = local_proofs.device
+        lp, ls = local_proofs.view(torch.int64).reshape(-1, 32), local_status.to(torch.int64)
+    else:
+        dev = device if device is not None else "cpu"
+        lp = torch.from_numpy(np.ascontiguousarray(local_proofs).view(np.int64).reshape(-1, 32)).to(dev)
+        ls = torch.from_numpy(local_status.astype(np.int64)).to(dev)
+    n = lp.shape[0]
+    if n > cap:
+        raise ValueError(f"shard of {n} proofs exceeds ceil({batch} / {world})")
     buf = torch.zeros((cap, 33), dtype=torch.int64, device=dev)
-    n = local_proofs.shape[0]
     if n:
-        buf[:n, :32] = torch.from_numpy(local_proofs.view(np.int64)).to(dev)
-        buf[:n, 32] = torch.from_numpy(local_status.astype(np.int64)).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)]
+        buf[:n, :32] = lp
+        buf[:n, 32] = ls
+    out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
-    proofs = np.zeros((batch, 32), dtype=np.uint64)
-    status = np.zeros(batch, dtype=np.int32)
+    parts_p, parts_s = [], []
     for r in range(world):
         lo, hi = shard_range(batch, r, world)
-        arr = out[r].cpu().numpy()
-        proofs[lo:hi] = arr[:hi - lo, :32].view(np.uint64)
-        status[lo:hi] = arr[:hi - lo, 32].astype(np.int32)
-    return proofs, status
+        parts_p.append(out[r][:hi - lo, :32])
+        parts_s.append(out[r][:hi - lo, 32])
+    proofs = torch.cat(parts_p)
+    status = torch.cat(parts_s).to(torch.int32)
+    if as_tensor:
+        return proofs, status
+    return (proofs.cpu().numpy().view(np.uint64).reshape(batch, 32),
+            status.cpu().numpy().astype(np.int32))
 
 
 def prove_sharded(prover_fn, inputs: np.ndarray, rs: np.ndarray, device=None):

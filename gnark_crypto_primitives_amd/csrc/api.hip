@@ -2,6 +2,8 @@
 // together: solve -> quotient (7 NTTs) -> 4 G1 MSMs + 1 G2 MSM -> assembly.
 // Stands in for groth16.Prove in gnark backend/groth16/bn254/prove.go [UPSTREAM-RECALL,
 // SURVEY.md §3.2].  There is no CPU fallback anywhere in this file.
+#include <algorithm>
+
 #include "zkmi_internal.h"
 #include "ff29.h"
 
@@ -24,8 +26,8 @@ int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out) {
     hipError_t e = hipMalloc(&s.p, bytes);
     if (e != hipSuccess) {
       ctx->err = "hipMalloc(" + std::to_string(bytes) + " B) failed: " + hipGetErrorString(e) +
-                 " (working set of this batch does not fit beside the MSM tables: load the key with"
-                 " a larger ZKMI_TABLE_RESERVE_GB, default 32)";
+                 " (the working set of this batch does not fit beside the MSM tables: load the key"
+                 " with zkmi_pk_desc.max_batch >= the batch size, or with a table_budget_bytes cap)";
       s.p = nullptr;
       return ZKMI_ERR_OOM;
     }
@@ -438,35 +440,32 @@ static bool window_bits_ok(int wb) {
 static WinPlan plan_explicit(int wb) {
   return wb >= 200 ? plan_comb(wb - 200) : wb >= 100 ? plan_shared(wb - 100) : plan_uniform(wb);
 }
-// auto plans: comb tables unless ZKMI_MSM_COMB=0
-static bool comb_default() {
-  static const bool v = [] {
-    const char* e = getenv("ZKMI_MSM_COMB");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
-}
 static const int COMB_WINDOWS = 254;
-// auto plans: shared tables unless ZKMI_MSM_SHARED=0 asks for the per-window layout
-static bool shared_default() {
-  static const bool v = [] {
-    const char* e = getenv("ZKMI_MSM_SHARED");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
+// HBM the prover needs beside the tables to prove batches of up to `max_batch` with a key of this
+// shape: two pipeline sets of {value file, a, b, c, staged inputs}, the NTT scratch,
+// the MSM integer scalars + digits + two partial-sum buffers, the per-set sums, the table-build
+// scratch that stays allocated, and a margin for the allocator.
+static double prove_working_set_bytes(uint32_t log_n, size_t n_slots, size_t n_in, size_t max_batch,
+                                      size_t n_msm_max) {
+  const double Bp = (double)round_up(max_batch ? max_batch : 1024, 64);
+  const double n = (double)((size_t)1 << log_n);
+  const double set = (double)n_slots * Bp * 32 + 3 * n * Bp * 32 + Bp * 100 + Bp * (n_in * 32 + 64);
+  const double digits = 254.0 * (double)((n_msm_max + 15) / 16) * Bp * 4;   // comb, k >= 16
+  const double sint = (double)n_msm_max * Bp * 32;
+  const double partials = 2 * 21.0 * 254 * Bp * 256;
+  const double sums = 2 * Bp * (7 * 128 + 2 * 256 + 256 + 256.0 * (4 * 128 + 256));
+  return 2 * set + n * Bp * 32 + digits + sint + partials + sums + 2e9 + 1e9;
 }
-static double usable_table_bytes() {
+static double free_hbm_bytes() {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  // reserve for the prover's working set (two pipeline sets of value file + a, b, c, NTT scratch,
-  // MSM digits and partials: ~23 GB at B = 1024 on the Arbo-160 circuit).  Bigger batches or
-  // circuits need more: ZKMI_TABLE_RESERVE_GB.
-  static const double reserve = [] {
-    const char* e = getenv("ZKMI_TABLE_RESERVE_GB");
-    const double v = e ? atof(e) : 32.0;
-    return (v < 1.0 ? 1.0 : v) * 1e9;
-  }();
-  const double usable = (double)free_b - reserve;
+  return (double)free_b;
+}
+// standalone base sets (zkmi_msm_bases_load): working set of a 1024-wide zkmi_msm_batch
+static double usable_table_bytes_standalone(size_t n) {
+  const double ws = (double)n * 1024 * 32 * 2 + 254.0 * ((n + 15) / 16) * 1024 * 4 +
+                    21.0 * 254 * 1024 * 256 + 3e9;
+  const double usable = free_hbm_bytes() - ws;
   return usable > 0 ? usable : 0.0;
 }
 
@@ -486,19 +485,16 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
     plan = plan_explicit(window_bits);
   } else {
     // per-window tables need no Horner tail: keep them when they reach as few windows as the
-    // shared table would (small base sets); otherwise one shared table per base
-    plan = plan_windows_for_budget(n, group, table_budget(group));
-    if (shared_default()) {
-      int c1, c2;
-      plan_shared_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(),
-                             &c1, &c2);
-      const WinPlan ps = plan_shared(group == 1 ? c1 : c2);
-      if (ps.W < plan.W) plan = ps;
-    }
-    if (comb_default() && n >= 64) {
+    // shared table would (small base sets); otherwise one shared table per base, or comb tables
+    const double usable = usable_table_bytes_standalone(n);
+    plan = plan_windows_for_budget(n, group, (group == 1 ? 0.64 : 0.34) * usable);
+    int c1, c2;
+    plan_shared_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable, &c1, &c2);
+    const WinPlan ps = plan_shared(group == 1 ? c1 : c2);
+    if (ps.W < plan.W) plan = ps;
+    if (n >= 64) {
       int k1, k2;
-      plan_comb_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable_table_bytes(),
-                           &k1, &k2);
+      plan_comb_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable, &k1, &k2);
       const int k = group == 1 ? k1 : k2;
       if ((double)COMB_WINDOWS / k < (double)plan.W) plan = plan_comb(k);
     }
@@ -605,33 +601,90 @@ void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk) {
   delete pk;
 }
 
+// wire index of every retained base from a gnark-style infinity map ([]bool, one byte per wire)
+static int wires_from_infinity(zkmi_ctx* ctx, const uint8_t* inf, uint32_t n_wires, uint32_t want,
+                               const char* name, std::vector<uint32_t>* out) {
+  std::vector<uint8_t> host(n_wires);
+  if (n_wires && hipMemcpy(host.data(), inf, n_wires, hipMemcpyDefault) != hipSuccess) {
+    ctx->err = std::string("pk: cannot read ") + name;
+    return ZKMI_ERR_HIP;
+  }
+  out->clear();
+  for (uint32_t i = 0; i < n_wires; i++)
+    if (!host[i]) out->push_back(i);
+  if (out->size() != want) {
+    ctx->err = std::string("pk: ") + name + " retains " + std::to_string(out->size()) +
+               " wires but the key holds " + std::to_string(want) + " points";
+    return ZKMI_ERR_ARG;
+  }
+  return ZKMI_OK;
+}
+
 int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   ZK_HIP(hipSetDevice(ctx->device));
   if (!d || !out) return ZKMI_ERR_ARG;
-  if (d->n_z + 1 != (1u << d->log_n)) {
-    ctx->err = "pk: n_z must equal 2^log_n - 1";
-    return ZKMI_ERR_ARG;
-  }
   if (d->log_n < 1 || d->log_n > 28) {
     ctx->err = "pk: log_n out of range [1,28]";
     return ZKMI_ERR_ARG;
   }
-  // every wire index is range-checked on the host before any kernel can use it as a row number
+  if (d->n_z + 1 != (1u << d->log_n)) {
+    ctx->err = "pk: n_z must equal 2^log_n - 1";
+    return ZKMI_ERR_ARG;
+  }
+  // wire index of every base: explicit arrays, or gnark's InfinityA / InfinityB / nbPublic
+  std::vector<uint32_t> wa, wb, wk;
   {
-    struct { const uint32_t* p; uint32_t n; const char* name; } idx[3] = {
-        {d->a_wire, d->n_a, "a_wire"}, {d->b_wire, d->n_b, "b_wire"}, {d->k_wire, d->n_k, "k_wire"}};
+    int rc;
+    struct { const uint32_t* p; uint32_t n; const char* name; std::vector<uint32_t>* v; } idx[3] = {
+        {d->a_wire, d->n_a, "a_wire", &wa}, {d->b_wire, d->n_b, "b_wire", &wb},
+        {d->k_wire, d->n_k, "k_wire", &wk}};
     for (auto& t : idx) {
-      std::vector<uint32_t> host(t.n);
-      if (t.n && hipMemcpy(host.data(), t.p, (size_t)t.n * 4, hipMemcpyDefault) != hipSuccess) {
+      if (!t.p) continue;
+      t.v->resize(t.n);
+      if (t.n && hipMemcpy(t.v->data(), t.p, (size_t)t.n * 4, hipMemcpyDefault) != hipSuccess) {
         ctx->err = std::string("pk: cannot read ") + t.name;
         return ZKMI_ERR_HIP;
       }
-      for (uint32_t i = 0; i < t.n; i++)
-        if (host[i] >= d->n_wires) {
+    }
+    if (!d->a_wire) {
+      if (!d->infinity_a) {
+        ctx->err = "pk: neither a_wire nor infinity_a given";
+        return ZKMI_ERR_ARG;
+      }
+      if ((rc = wires_from_infinity(ctx, d->infinity_a, d->n_wires, d->n_a, "infinity_a", &wa)))
+        return rc;
+    }
+    if (!d->b_wire) {
+      if (!d->infinity_b) {
+        ctx->err = "pk: neither b_wire nor infinity_b given";
+        return ZKMI_ERR_ARG;
+      }
+      if ((rc = wires_from_infinity(ctx, d->infinity_b, d->n_wires, d->n_b, "infinity_b", &wb)))
+        return rc;
+    }
+    if (!d->k_wire) {
+      if (d->n_public < 1 || d->n_public > d->n_wires || d->n_wires - d->n_public != d->n_k) {
+        ctx->err = "pk: without k_wire, n_public must satisfy n_wires - n_public == n_k";
+        return ZKMI_ERR_ARG;
+      }
+      wk.resize(d->n_k);
+      for (uint32_t i = 0; i < d->n_k; i++) wk[i] = d->n_public + i;
+    }
+    // every wire index is range-checked on the host before any kernel can use it as a row number
+    for (auto& t : idx)
+      for (uint32_t w : *t.v)
+        if (w >= d->n_wires) {
           ctx->err = std::string("pk: ") + t.name + " holds a wire index >= n_wires";
           return ZKMI_ERR_ARG;
         }
-    }
+  }
+  if (!window_bits_ok((int)d->window_bits_g1) || !window_bits_ok((int)d->window_bits_g2)) {
+    ctx->err = "pk: window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
+    return ZKMI_ERR_ARG;
+  }
+  if (d->msm_chunk_factor > 64) {
+    ctx->err = "pk: msm_chunk_factor must be in [0,64]";
+    return ZKMI_ERR_ARG;
   }
   auto* pk = new zkmi_pk();
   pk->log_n = d->log_n;
@@ -640,31 +693,35 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   pk->n_b = d->n_b;
   pk->n_k = d->n_k;
   pk->n_z = d->n_z;
+  pk->max_batch = d->max_batch ? d->max_batch : 1024;
   int rc;
-  // one window plan per group for the whole key, sized against free HBM
+  // One window plan per group for the whole key.  Auto plans are sized against the free HBM minus
+  // the working set of the largest batch the caller will prove (and the caller's own cap).
   const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
-  if (!window_bits_ok((int)d->window_bits_g1) || !window_bits_ok((int)d->window_bits_g2)) {
-    ctx->err = "pk: window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
-    delete pk;
-    return ZKMI_ERR_ARG;
-  }
   const size_t n1 = (size_t)d->n_a + d->n_b + d->n_k + d->n_z;
-  int sc1 = 0, sc2 = 0;
-  if (shared_default()) plan_shared_for_budget(n1, d->n_b, usable_table_bytes(), &sc1, &sc2);
+  const size_t n_msm_max = std::max(std::max((size_t)d->n_a, (size_t)d->n_b),
+                                    std::max((size_t)d->n_k, (size_t)d->n_z));
+  const size_t n_slots = d->n_slots_hint ? d->n_slots_hint : (size_t)d->n_wires + d->n_wires / 20;
+  const double ws = prove_working_set_bytes(d->log_n, n_slots, d->n_wires, pk->max_batch, n_msm_max);
+  double usable = free_hbm_bytes() - ws;
+  if (usable < 0) usable = 0;
+  if (d->table_budget_bytes && (double)d->table_budget_bytes < usable)
+    usable = (double)d->table_budget_bytes;
   // auto: per-window tables when they reach as few windows as a shared table would (small keys:
   // no Horner tail), otherwise one shared table per base
-  WinPlan p1 = auto1 ? plan_windows_for_budget(n1, 1, table_budget(1))
+  int sc1 = 0, sc2 = 0;
+  plan_shared_for_budget(n1, d->n_b, 0.98 * usable, &sc1, &sc2);
+  WinPlan p1 = auto1 ? plan_windows_for_budget(n1, 1, 0.64 * usable)
                      : plan_explicit((int)d->window_bits_g1);
-  WinPlan p2 = auto2 ? plan_windows_for_budget(d->n_b, 2, table_budget(2))
+  WinPlan p2 = auto2 ? plan_windows_for_budget(d->n_b, 2, 0.34 * usable)
                      : plan_explicit((int)d->window_bits_g2);
   if (auto1 && sc1 && plan_shared(sc1).W < p1.W) p1 = plan_shared(sc1);
   if (auto2 && sc2 && plan_shared(sc2).W < p2.W) p2 = plan_shared(sc2);
   // comb tables (joint tables over k bases) when they need fewer additions per base still; small
   // keys keep the layouts above (their MSMs are latency, not throughput)
-  if (comb_default() && n1 >= 4096) {
+  if (n1 >= 4096) {
     int k1 = 0, k2 = 0;
-    plan_comb_for_budget(auto1 ? n1 : 0, auto2 ? d->n_b : 0,
-                         usable_table_bytes() - (auto1 ? 0.0 : 0.0), &k1, &k2);
+    plan_comb_for_budget(auto1 ? n1 : 0, auto2 ? d->n_b : 0, 0.98 * usable, &k1, &k2);
     if (auto1 && (double)COMB_WINDOWS / k1 < (double)p1.W) p1 = plan_comb(k1);
     if (auto2 && (double)COMB_WINDOWS / k2 < (double)p2.W) p2 = plan_comb(k2);
   }
@@ -673,11 +730,13 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
     Staged sb(ctx);
     int r = sb.in(pts, n * (group == 1 ? 64 : 128));
     if (r) return r;
-    return bases_load_plan(ctx, group, sb.dev, n, plan, relax, out);
+    r = bases_load_plan(ctx, group, sb.dev, n, plan, relax, out);
+    if (!r) (*out)->chunk_factor = d->msm_chunk_factor;
+    return r;
   };
-  if ((rc = upload_u32(ctx, d->a_wire, d->n_a, &pk->a_wire)) ||
-      (rc = upload_u32(ctx, d->b_wire, d->n_b, &pk->b_wire)) ||
-      (rc = upload_u32(ctx, d->k_wire, d->n_k, &pk->k_wire)) ||
+  if ((rc = upload_u32(ctx, wa.data(), d->n_a, &pk->a_wire)) ||
+      (rc = upload_u32(ctx, wb.data(), d->n_b, &pk->b_wire)) ||
+      (rc = upload_u32(ctx, wk.data(), d->n_k, &pk->k_wire)) ||
       (rc = load(1, d->g1_a, d->n_a, p1, auto1, &pk->A)) ||
       (rc = load(1, d->g1_b, d->n_b, p1, auto1, &pk->B1)) ||
       (rc = load(1, d->g1_k, d->n_k, p1, auto1, &pk->K)) ||
@@ -781,6 +840,10 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
                std::to_string(d->n_constraints);
     return ZKMI_ERR_ARG;
   }
+  if (d->solve_block != 0 && d->solve_block != 64 && d->solve_block != 128 && d->solve_block != 256) {
+    ctx->err = "cs: solve_block must be 0, 64, 128 or 256";
+    return ZKMI_ERR_ARG;
+  }
   auto* cs = new zkmi_cs();
   cs->n_wires = d->n_wires;
   cs->n_public = d->n_public;
@@ -789,6 +852,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   cs->n_slots = d->n_slots;
   cs->n_ops = d->n_ops;
   cs->n_consts = d->n_consts;
+  cs->solve_block = d->solve_block;
   int rc = upload_u32(ctx, d->program, (size_t)(d->n_ops + 1) * 4, &cs->program);
   if (rc) {
     delete cs;
@@ -959,6 +1023,8 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
   S.Bp = Bp;
   S.pk = pk;
   S.cs = cs;
+  S.n_constraints = cs->n_constraints;
+  S.f_domain = true;
   ctx->next_submit ^= 1;
   return ZKMI_OK;
 }
@@ -995,7 +1061,7 @@ struct SumsView {
 static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   zkmi_ctx::ProveSet& S = ctx->sets[si];
   const zkmi_pk* pk = S.pk;
-  const zkmi_cs* cs = S.cs;
+  const bool fd = S.f_domain;
   const size_t Bp = S.Bp, n = (size_t)1 << pk->log_n;
   NttPlan* plan;
   int rc = get_plan(ctx, (int)pk->log_n, &plan);
@@ -1008,8 +1074,8 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   ZK_HIP(hipStreamWaitEvent(ctx->stream, S.ev1, 0));
   hipEventRecord(S.evq[0], ctx->stream);
   Fr* h;
-  if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, cs->n_constraints,
-                         &h, true)))
+  if ((rc = compute_h_bi(ctx, plan, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (Fr*)t0, Bp, S.n_constraints,
+                         &h, fd)))
     return rc;
   hipEventRecord(S.evq[1], ctx->stream);
   S.msm_ev_used = 0;
@@ -1018,15 +1084,15 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   const bool d1 = pk->Z->plan.shared || pk->Z->plan.comb;
   const bool d2 = pk->B2->plan.shared || pk->B2->plan.comb;
   hipStream_t q3 = ctx->stream3;
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, true, d1 ? v.w1[0] : nullptr, q3)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, true, d1 ? v.w1[1] : nullptr, q3)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, true, d1 ? v.w1[2] : nullptr, q3)) ||
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, fd, d1 ? v.w1[0] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, fd, d1 ? v.w1[1] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, fd, d1 ? v.w1[2] : nullptr, q3)) ||
       (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr, q3))) {
     ctx->msm_ev_set = -1;
     return rc;
   }
   hipEventRecord(S.evq[2], ctx->stream);
-  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, true, d2 ? v.w2 : nullptr, q3);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, fd, d2 ? v.w2 : nullptr, q3);
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);
@@ -1128,6 +1194,77 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
   int rc = zkmi_prove_submit(ctx, pk, cs, inputs, batch, rs);
   if (rc) return rc;
   return zkmi_prove_collect(ctx, proofs_out, status_out);
+}
+
+// Stage 1 replaced by the caller's own solver: wires and a, b, c arrive solved, in gnark's image.
+int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires, const void* a,
+                             const void* b, const void* c, size_t n_constraints, size_t batch,
+                             const void* rs, void* proofs_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (batch == 0) return ZKMI_OK;
+  if (any_pending(ctx)) {
+    ctx->err = "prove_witness_batch: batches submitted with zkmi_prove_submit are still in flight";
+    return ZKMI_ERR_ARG;
+  }
+  if (!pk || !wires || !a || !b || !c || !rs || !proofs_out) {
+    ctx->err = "prove_witness_batch: null argument";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n;
+  if (n_constraints == 0 || n_constraints > n) {
+    ctx->err = "prove_witness_batch: n_constraints must be in [1, 2^log_n]";
+    return ZKMI_ERR_ARG;
+  }
+  const int si = ctx->next_submit;
+  zkmi_ctx::ProveSet& S = ctx->sets[si];
+  const size_t Bp = round_up(batch, 64);
+  const size_t nw = pk->n_wires;
+  int rc;
+  const int base = si == 0 ? 0 : 8;
+  void* misc;
+  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15,
+                           Bp * (7 * 128 + 2 * 256 + 256 + 256 * (4 * 128 + 256)), &S.sums)) ||
+      (rc = ensure_scratch(ctx, base + 0, nw * Bp * 32, &S.slots)) ||
+      (rc = ensure_scratch(ctx, base + 1, n * Bp * 32, &S.a)) ||
+      (rc = ensure_scratch(ctx, base + 2, n * Bp * 32, &S.b)) ||
+      (rc = ensure_scratch(ctx, base + 3, n * Bp * 32, &S.c)) ||
+      (rc = ensure_scratch(ctx, base + 5, Bp * (96 + 4), &misc)))
+    return rc;
+  S.rs = misc;
+  S.st = (char*)misc + Bp * 96;
+  S.heavy_enqueued = false;
+  {
+    // proof-major host or device buffers -> batch-inner rows, on the second stream like a submit
+    Staged sw(ctx), sa(ctx), sb(ctx), sc(ctx), sr(ctx);
+    hipStream_t saved = ctx->stream;
+    ctx->stream = ctx->stream2;
+    hipEventRecord(S.ev0, ctx->stream);
+    rc = sw.in(wires, batch * nw * 32);
+    if (!rc) rc = sa.in(a, batch * n_constraints * 32);
+    if (!rc) rc = sb.in(b, batch * n_constraints * 32);
+    if (!rc) rc = sc.in(c, batch * n_constraints * 32);
+    if (!rc) rc = sr.in(rs, batch * 64);
+    if (!rc) rc = transpose_in(ctx, sw.dev, S.slots, nw, batch, Bp, 32);
+    if (!rc) rc = transpose_in(ctx, sa.dev, S.a, n_constraints, batch, Bp, 32);
+    if (!rc) rc = transpose_in(ctx, sb.dev, S.b, n_constraints, batch, Bp, 32);
+    if (!rc) rc = transpose_in(ctx, sc.dev, S.c, n_constraints, batch, Bp, 32);
+    if (!rc) rc = transpose_in(ctx, sr.dev, S.rs, 2, batch, Bp, 32);
+    if (!rc && hipMemsetAsync(S.st, 0, Bp * 4, ctx->stream) != hipSuccess) rc = ZKMI_ERR_HIP;
+    hipEventRecord(S.ev1, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = ZKMI_ERR_HIP;  // staging buffers go away
+    ctx->stream = saved;
+    if (rc) return rc;
+  }
+  S.pending = true;
+  S.batch = batch;
+  S.Bp = Bp;
+  S.pk = pk;
+  S.cs = nullptr;
+  S.n_constraints = n_constraints;
+  S.f_domain = false;
+  ctx->next_submit ^= 1;
+  std::vector<int32_t> status(batch);
+  return zkmi_prove_collect(ctx, proofs_out, status.data());
 }
 
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out) {

@@ -4,8 +4,30 @@
 #pragma once
 #include "ec.h"
 #include "ff29.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "ff29_asm.h"
+#endif
 
 namespace zk {
+
+// Field products of the MSM inner loop: on the device the single-accumulator asm chains of
+// ff29_asm.h (no v_lshl_add_u64 merges: 2192 -> ~2010 instructions per G1 mixed addition), on the
+// host (tests/native/test_ff29.cpp) the C++ forms they restate.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class P> ZK_HD F29<P> mmul(const F29<P>& a, const F29<P>& b) { return mul_asm(a, b); }
+template <class P> ZK_HD F29<P> msqr(const F29<P>& a) { return sqr_asm(a); }
+template <class P>
+ZK_HD F29<P> mmul_add2(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+  return mul_add2_asm(a, b, c, d);
+}
+#else
+template <class P> ZK_HD F29<P> mmul(const F29<P>& a, const F29<P>& b) { return mul(a, b); }
+template <class P> ZK_HD F29<P> msqr(const F29<P>& a) { return sqr(a); }
+template <class P>
+ZK_HD F29<P> mmul_add2(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d) {
+  return mul_add2(a, b, c, d);
+}
+#endif
 
 // Invariants between calls: x, y normalised with |x| < 5p, |y| < 2p; zz, zzz mul outputs.
 struct G1Acc29 {
@@ -52,10 +74,12 @@ ZK_HD void opaque_limbs(Fq29& a) {
 }
 
 ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
+#if !defined(__HIP_DEVICE_COMPILE__)
   opaque_limbs(acc.x);
   opaque_limbs(acc.y);
   opaque_limbs(acc.zz);
   opaque_limbs(acc.zzz);
+#endif
   if (acc.inf) {
     acc.x = qx;
     acc.y = norm(qy);
@@ -63,12 +87,12 @@ ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
     acc.inf = false;
     return;
   }
-  const Fq29 u2 = mul(qx, acc.zz);
-  const Fq29 s2 = mul(qy, acc.zzz);
+  const Fq29 u2 = mmul(qx, acc.zz);
+  const Fq29 s2 = mmul(qy, acc.zzz);
   const Fq29 p = sub(u2, acc.x);  // |limbs| < 2^29, |value| < 6.5p
   const Fq29 r = sub(s2, acc.y);  // |value| < 3.5p
-  const Fq29 pp = sqr(p);
-  const Fq29 rr = sqr(r);
+  const Fq29 pp = msqr(p);
+  const Fq29 rr = msqr(r);
   if (is_zero_mulout(pp)) {  // same x: doubling or cancellation (never on honest random data)
     if (is_zero_mulout(rr))
       mdbl29(acc, qx, qy);
@@ -76,19 +100,35 @@ ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
       acc.inf = true;
     return;
   }
-  const Fq29 ppp = mul(p, pp);
-  const Fq29 q = mul(acc.x, pp);
+  const Fq29 ppp = mmul(p, pp);
+  const Fq29 q = mmul(acc.x, pp);
   const Fq29 x3 = norm(sub(sub(rr, ppp), add(q, q)));  // (-5p, 3p)
   // y3 = r*(q - x3) - y1*ppp with ONE Montgomery reduction for both products (saves 90 of the
   // 342 mads and the normalisation); |r (q-x3)| + |y1 ppp| < 26 p^2, result in (-p/2, 3p/2)
-  const Fq29 y3 = mul_add2(r, sub(q, x3), neg(acc.y), ppp);
-  acc.zz = mul(acc.zz, pp);
-  acc.zzz = mul(acc.zzz, ppp);
+  const Fq29 y3 = mmul_add2(r, sub(q, x3), neg(acc.y), ppp);
+  acc.zz = mmul(acc.zz, pp);
+  acc.zzz = mmul(acc.zzz, ppp);
   acc.x = x3;
   acc.y = y3;
 }
 
 // ---- G2 (Fq2 components, lazy reduction) -------------------------------------------------------
+// ff29.h's Fq2 product and square.  The G2 kernels run two waves per SIMD, so on the device the two
+// components (independent products) are interleaved in one asm block with two accumulator chains.
+#if defined(__HIP_DEVICE_COMPILE__)
+ZK_HD Fq2_29 mmul(const Fq2_29& a, const Fq2_29& b) {
+  const auto r = mul_add2_x2_asm(a.c0, b.c0, neg(a.c1), b.c1, a.c1);
+  return {r.lo, r.hi};
+}
+ZK_HD Fq2_29 msqr(const Fq2_29& a) {
+  const auto r = mul_x2_asm(add(a.c0, a.c1), sub(a.c0, a.c1), add(a.c0, a.c0), a.c1);
+  return {r.lo, r.hi};
+}
+#else
+ZK_HD Fq2_29 mmul(const Fq2_29& a, const Fq2_29& b) { return mul(a, b); }
+ZK_HD Fq2_29 msqr(const Fq2_29& a) { return sqr(a); }
+#endif
+
 // Invariants between calls: x, y weakly reduced (|component| < 0.6p); zz, zzz products.
 struct G2Acc29 {
   Fq2_29 x, y, zz, zzz;
@@ -119,6 +159,7 @@ ZK_HD void mdbl29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
 
 // qx canonical components, qy canonical or limb-wise negated
 ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
+#if !defined(__HIP_DEVICE_COMPILE__)
   opaque_limbs(acc.x.c0);    // see the G1 madd29
   opaque_limbs(acc.x.c1);
   opaque_limbs(acc.y.c0);
@@ -127,6 +168,7 @@ ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
   opaque_limbs(acc.zz.c1);
   opaque_limbs(acc.zzz.c0);
   opaque_limbs(acc.zzz.c1);
+#endif
   if (acc.inf) {
     acc.x = qx;
     acc.y = norm(qy);
@@ -134,12 +176,12 @@ ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
     acc.inf = false;
     return;
   }
-  const Fq2_29 u2 = mul(qx, acc.zz);
-  const Fq2_29 s2 = mul(qy, acc.zzz);
+  const Fq2_29 u2 = mmul(qx, acc.zz);
+  const Fq2_29 s2 = mmul(qy, acc.zzz);
   const Fq2_29 p = sub(u2, acc.x);  // |component| < 1.7p, |limb| < 2^29
   const Fq2_29 r = sub(s2, acc.y);
-  const Fq2_29 pp = sqr(p);
-  const Fq2_29 rr = sqr(r);
+  const Fq2_29 pp = msqr(p);
+  const Fq2_29 rr = msqr(r);
   if (is_zero_mulout(pp)) {
     if (is_zero_mulout(rr))
       mdbl29(acc, qx, qy);
@@ -147,12 +189,12 @@ ZK_HD void madd29(G2Acc29& acc, const Fq2_29& qx, const Fq2_29& qy) {
       acc.inf = true;
     return;
   }
-  const Fq2_29 ppp = mul(p, pp);
-  const Fq2_29 q = mul(acc.x, pp);
+  const Fq2_29 ppp = mmul(p, pp);
+  const Fq2_29 q = mmul(acc.x, pp);
   const Fq2_29 x3 = wred(sub(sub(rr, ppp), add(q, q)));
-  const Fq2_29 y3 = wred(sub(mul(r, sub(q, x3)), mul(acc.y, ppp)));
-  acc.zz = mul(acc.zz, pp);
-  acc.zzz = mul(acc.zzz, ppp);
+  const Fq2_29 y3 = wred(sub(mmul(r, sub(q, x3)), mmul(acc.y, ppp)));
+  acc.zz = mmul(acc.zz, pp);
+  acc.zzz = mmul(acc.zzz, ppp);
   acc.x = x3;
   acc.y = y3;
 }

@@ -602,16 +602,6 @@ void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, 
       }
     }
 }
-// Table budgets against free HBM: a reserve for the prover's working set (two pipeline sets of
-// value file + a, b, c, NTT scratch, MSM partials: ~25 GB at B = 1024, Arbo-160), then 64 % of the
-// rest for the G1 bases of a key and 34 % for its G2 bases.  Arbo-160 on a 288 GiB MI355X:
-// 25 windows for G1 (5 x 11 + 20 x 10 bits, 170 GB), 23 for G2 (2 x 12 + 21 x 11 bits, 89 GB).
-double table_budget(int group) {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-  const double usable = (double)free_b - 28e9;
-  return (group == 1 ? 0.64 : 0.34) * (usable > 0 ? usable : 0.0);
-}
 WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes) {
   const double entry = group == 1 ? 64.0 : 128.0;
   for (int W = 16; W <= 64; W++) {
@@ -761,11 +751,8 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     const uint32_t k = bases->plan.comb;
     const size_t G = bases->n_groups;
     const int W = COMB_W;
-    static const size_t comb_factor = [] {
-      const char* e = getenv("ZKMI_MSM_CHUNKS");
-      const long v = e ? atol(e) : 16;   // measured 4 / 8 / 12 / 16 / 24: 277 / 275 / 273.5 / 272 / 273.6 ms
-      return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
-    }();
+    // measured at 4 / 8 / 12 / 16 / 24: 277 / 275 / 273.5 / 272 / 273.6 ms per Arbo-160 batch
+    const size_t comb_factor = bases->chunk_factor ? bases->chunk_factor : 16;
     size_t chunks = comb_factor * 262144 / Bp / (size_t)W;
     if (chunks < 1) chunks = 1;
     if (chunks > G) chunks = G;
@@ -859,11 +846,7 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
       }
     }
     // (window, chunk) blocks: 8 x the wave slots of the chip, as for the per-window tables
-    static const size_t shared_factor = [] {
-      const char* e = getenv("ZKMI_MSM_CHUNKS");
-      const long v = e ? atol(e) : 8;
-      return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
-    }();
+    const size_t shared_factor = bases->chunk_factor ? bases->chunk_factor : 8;
     size_t chunks = shared_factor * 262144 / Bp / (size_t)W;
     if (chunks < 1) chunks = 1;
     if (chunks > n) chunks = n;

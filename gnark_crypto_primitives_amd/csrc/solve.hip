@@ -249,13 +249,9 @@ int array_to_f_domain(zkmi_ctx* ctx, Fr* a, size_t n) {
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
              size_t Bp) {
   hipLaunchKernelGGL(fill_one_row, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, slots, Bp);
-  // ZKMI_SOLVE_BLOCK: lanes per block (64 spreads the 16 waves of a 1024-proof batch over 16 CUs,
-  // 256 packs them on 4)
-  static const unsigned sb = [] {
-    const char* e = getenv("ZKMI_SOLVE_BLOCK");
-    const long v = e ? atol(e) : 64;
-    return (unsigned)(v == 128 || v == 256 ? v : 64);
-  }();
+  // lanes per block (zkmi_cs_desc.solve_block): 64 spreads the 16 waves of a 1024-proof batch over
+  // 16 CUs, 256 packs them on 4
+  const unsigned sb = cs->solve_block ? cs->solve_block : 64;
   const unsigned bs = (Bp % sb == 0) ? sb : 64;
   hipLaunchKernelGGL(solve_kernel, dim3((unsigned)(Bp / bs)), dim3(bs), 0, ctx->stream,
                      (const uint4*)cs->program, cs->consts, slots, a, b, c, status, Bp, cs->n_ops);

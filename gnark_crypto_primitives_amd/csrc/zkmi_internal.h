@@ -70,7 +70,9 @@ struct zkmi_ctx {
     int msm_ev_used = 0;
     size_t batch = 0, Bp = 0;
     const zkmi_pk* pk = nullptr;
-    const zkmi_cs* cs = nullptr;
+    const zkmi_cs* cs = nullptr;      // null for zkmi_prove_witness_batch (solved by the caller)
+    size_t n_constraints = 0;         // rows of a, b, c that hold data (the rest of the domain is 0)
+    bool f_domain = true;             // value file and a, b, c in the solver's 2^261 domain
     void *slots = nullptr, *a = nullptr, *b = nullptr, *c = nullptr, *rs = nullptr, *st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // solve start / end on stream2
   } sets[2];
@@ -112,10 +114,11 @@ struct zkmi_msm_bases {
   uint8_t* inf = nullptr;  // device, n flags: base i is the point at infinity (skipped)
   size_t n_groups = 0;     // comb plans: ceil(n / k)
   int entries_may_be_inf = 0;  // comb plans: some subset of a group sums to the identity
+  uint32_t chunk_factor = 0;   // (window, chunk) blocks in flight / wave slots; 0 = default
 };
 
 struct zkmi_pk {
-  uint32_t log_n = 0, n_wires = 0, n_a = 0, n_b = 0, n_k = 0, n_z = 0;
+  uint32_t log_n = 0, n_wires = 0, n_a = 0, n_b = 0, n_k = 0, n_z = 0, max_batch = 1024;
   uint32_t *a_wire = nullptr, *b_wire = nullptr, *k_wire = nullptr;  // device
   zkmi_msm_bases *A = nullptr, *B1 = nullptr, *K = nullptr, *Z = nullptr, *B2 = nullptr;
   zkmi_msm_bases *D1 = nullptr, *D2 = nullptr;  // one-base tables of delta (G1, G2)
@@ -126,7 +129,7 @@ struct zkmi_pk {
 
 struct zkmi_cs {
   uint32_t n_wires = 0, n_public = 0, n_secret = 0, n_constraints = 0, n_slots = 0, n_ops = 0,
-           n_consts = 0;
+           n_consts = 0, solve_block = 0;
   uint32_t* program = nullptr;  // device
   zk::Fr* consts = nullptr;     // device
 };
@@ -200,7 +203,6 @@ int compute_h_bi(zkmi_ctx* ctx, const NttPlan* plan, Fr* a, Fr* b, Fr* c, Fr* t0
 WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes);
 WinPlan plan_uniform(int c);
 WinPlan plan_with_windows(int W);
-double table_budget(int group);
 int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, const WinPlan& plan,
                     zkmi_msm_bases** out);
 // scalars batch-inner: element (row, b) at scalars[row * Bp + b]; row_idx (device, may be null)

@@ -66,6 +66,15 @@ class ProvingKey:
     def nbytes(self):
         return sum(x.nbytes for x in (self.g1_a, self.g1_b, self.g1_k, self.g1_z, self.g2_b))
 
+    def infinity_maps(self):
+        """gnark's ProvingKey.InfinityA / InfinityB ([]bool over all wires: True = the point is at
+        infinity and not stored), as uint8 arrays."""
+        inf_a = np.ones(self.n_wires, dtype=np.uint8)
+        inf_b = np.ones(self.n_wires, dtype=np.uint8)
+        inf_a[self.a_wire] = 0
+        inf_b[self.b_wire] = 0
+        return inf_a, inf_b
+
 
 class VerifyingKey:
     def __init__(self):
@@ -154,21 +163,38 @@ class Prover:
     """Device-resident (constraint system, proving key) pair; ``prove`` = one zkmi_prove_batch."""
 
     def __init__(self, ctx: _lib.Context, cc: CompiledCircuit, pk: ProvingKey,
-                 window_bits_g1: int = 0, window_bits_g2: int = 0):
+                 window_bits_g1: int = 0, window_bits_g2: int = 0, *, max_batch: int = 0,
+                 table_budget_bytes: int = 0, msm_chunk_factor: int = 0, solve_block: int = 0,
+                 gnark_key_layout: bool = False):
+        """max_batch / table_budget_bytes / msm_chunk_factor / solve_block: zkmi_pk_desc /
+        zkmi_cs_desc plan fields (0 = default).  gnark_key_layout: describe the key the way
+        gnark's ProvingKey does (InfinityA / InfinityB byte maps + nbPublic) instead of wire-index
+        arrays; the loaded key is the same."""
         self.ctx, self.cc, self.pk = ctx, cc, pk
         self.n_inputs = cc.n_inputs
         self._consts = to_mont_array(cc.consts) if cc.consts else np.zeros((0, 4), np.uint64)
         prog = self._prog = np.ascontiguousarray(cc.program, dtype=np.uint32)
         cd = _lib.CsDesc(cc.n_wires, cc.n_public, cc.n_secret, cc.n_constraints, cc.n_slots,
-                         cc.n_ops, len(cc.consts), 0, prog.ctypes.data, self._consts.ctypes.data)
+                         cc.n_ops, len(cc.consts), solve_block, prog.ctypes.data,
+                         self._consts.ctypes.data)
         self.cs_h = ctx.cs_load(cd)
         self._keep = [np.ascontiguousarray(x) for x in
                       (pk.a_wire, pk.b_wire, pk.k_wire, pk.g1_a, pk.g1_b, pk.g1_k, pk.g1_z, pk.g2_b,
                        pk.g1_alpha, pk.g1_beta, pk.g1_delta, pk.g2_beta, pk.g2_delta)]
         k = self._keep
+        ptrs = [x.ctypes.data for x in k]
+        inf_a = inf_b = None
+        n_public = 0
+        if gnark_key_layout:
+            inf_a, inf_b = pk.infinity_maps()
+            self._keep += [inf_a, inf_b]
+            ptrs[0] = ptrs[1] = ptrs[2] = None
+            n_public = cc.n_public
         pd = _lib.PkDesc(pk.log_n, pk.n_wires, len(pk.a_wire), len(pk.b_wire), len(pk.k_wire),
-                         pk.g1_z.shape[0], *[x.ctypes.data for x in k], window_bits_g1,
-                         window_bits_g2)
+                         pk.g1_z.shape[0], *ptrs, window_bits_g1, window_bits_g2,
+                         inf_a.ctypes.data if inf_a is not None else None,
+                         inf_b.ctypes.data if inf_b is not None else None, n_public,
+                         max_batch, table_budget_bytes, cc.n_slots, msm_chunk_factor)
         self.pk_h = ctx.pk_load(pd)
 
     def close(self):
@@ -182,6 +208,7 @@ class Prover:
     def solve(self, inputs, want_wires=True, want_abc=False):
         """Witness solve only (cs.R1CS.Solve).  inputs: [batch, n_inputs, 4] Montgomery."""
         batch = inputs.shape[0]
+        self._check_batch(inputs, (batch, self.n_inputs, 4), "inputs")
         wires = np.zeros((batch, self.cc.n_wires, 4), np.uint64) if want_wires else None
         abc = np.zeros((3, batch, self.cc.n_constraints, 4), np.uint64) if want_abc else None
         status = self.ctx.solve_batch(self.cs_h, np.ascontiguousarray(inputs), batch, wires, abc)
@@ -191,6 +218,8 @@ class Prover:
         """inputs: [batch, n_inputs, 4] (numpy) or a device tensor; rs: [batch, 2, 4].
         Returns (proofs [batch, 32] uint64: Ar | Krs | Bs, status [batch] int32)."""
         batch = inputs.shape[0]
+        self._check_batch(inputs, (batch, self.n_inputs, 4), "inputs")
+        self._check_batch(rs, (batch, 2, 4), "rs")
         if proofs_out is None:
             proofs_out = np.zeros((batch, 32), dtype=np.uint64)
         if status_out is None:
@@ -198,8 +227,37 @@ class Prover:
         self.ctx.prove_batch(self.pk_h, self.cs_h, inputs, batch, rs, proofs_out, status_out)
         return proofs_out, status_out
 
+    def prove_witness(self, wires, a, b, c, rs, proofs_out=None):
+        """groth16.Prove from solved witnesses (zkmi_prove_witness_batch): ``wires`` [batch,
+        n_wires, 4] full wire vectors (ONE first), ``a``/``b``/``c`` [batch, n_constraints, 4]
+        constraint evaluations, all in gnark's Montgomery image -- what gnark's own solver yields."""
+        batch = wires.shape[0]
+        self._check_batch(wires, (batch, self.cc.n_wires, 4), "wires")
+        for name, x in (("a", a), ("b", b), ("c", c)):
+            self._check_batch(x, (batch, self.cc.n_constraints, 4), name)
+        self._check_batch(rs, (batch, 2, 4), "rs")
+        if proofs_out is None:
+            proofs_out = np.zeros((batch, 32), dtype=np.uint64)
+        self.ctx.prove_witness_batch(self.pk_h, wires, a, b, c, self.cc.n_constraints, batch, rs,
+                                     proofs_out)
+        return proofs_out
+
+    @staticmethod
+    def _check_batch(x, shape, name):
+        """The C ABI takes raw pointers: refuse anything that is not the documented layout."""
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(x.shape)}")
+        if isinstance(x, np.ndarray):
+            if x.dtype != np.uint64 or not x.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"{name}: expected a C-contiguous uint64 array")
+        elif hasattr(x, "is_contiguous"):
+            if not x.is_contiguous() or x.element_size() != 8:
+                raise ValueError(f"{name}: expected a contiguous 64-bit tensor")
+
     def submit(self, inputs, rs):
         """Stage 1 (inputs + witness solve) of a batch; overlaps the previous batch's stage 2."""
+        self._check_batch(inputs, (inputs.shape[0], self.n_inputs, 4), "inputs")
+        self._check_batch(rs, (inputs.shape[0], 2, 4), "rs")
         self.ctx.prove_submit(self.pk_h, self.cs_h, inputs, inputs.shape[0], rs)
         self._inflight = getattr(self, "_inflight", [])
         self._inflight.append((inputs, rs, inputs.shape[0]))     # keep buffers alive

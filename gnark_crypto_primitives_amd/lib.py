@@ -25,13 +25,16 @@ class PkDesc(C.Structure):
                 ("g1_z", C.c_void_p), ("g2_b", C.c_void_p), ("g1_alpha", C.c_void_p),
                 ("g1_beta", C.c_void_p), ("g1_delta", C.c_void_p), ("g2_beta", C.c_void_p),
                 ("g2_delta", C.c_void_p), ("window_bits_g1", C.c_uint32),
-                ("window_bits_g2", C.c_uint32)]
+                ("window_bits_g2", C.c_uint32),
+                ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("n_public", C.c_uint32),
+                ("max_batch", C.c_uint32), ("table_budget_bytes", C.c_uint64),
+                ("n_slots_hint", C.c_uint32), ("msm_chunk_factor", C.c_uint32)]
 
 
 class CsDesc(C.Structure):
     _fields_ = [("n_wires", C.c_uint32), ("n_public", C.c_uint32), ("n_secret", C.c_uint32),
                 ("n_constraints", C.c_uint32), ("n_slots", C.c_uint32), ("n_ops", C.c_uint32),
-                ("n_consts", C.c_uint32), ("_pad", C.c_uint32), ("program", C.c_void_p),
+                ("n_consts", C.c_uint32), ("solve_block", C.c_uint32), ("program", C.c_void_p),
                 ("consts", C.c_void_p)]
 
 
@@ -60,6 +63,7 @@ SYMBOLS = [
     ("zkmi_prove_batch", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P]),
     ("zkmi_prove_submit", _I, [_P, _P, _P, _P, _SZ, _P]),
     ("zkmi_prove_collect", _I, [_P, _P, _P]),
+    ("zkmi_prove_witness_batch", _I, [_P, _P, _P, _P, _P, _P, _SZ, _SZ, _P, _P]),
     ("zkmi_last_timings", _I, [_P, C.POINTER(C.c_double)]),
 ]
 
@@ -219,6 +223,12 @@ class Context:
     def prove_collect(self, proofs_out, status_out):
         self._check(self.lib.zkmi_prove_collect(self.h, _ptr(proofs_out), _ptr(status_out)),
                     "zkmi_prove_collect")
+
+    def prove_witness_batch(self, pk_h, wires, a, b, c, n_constraints, batch, rs, proofs_out):
+        self._check(self.lib.zkmi_prove_witness_batch(self.h, pk_h, _ptr(wires), _ptr(a), _ptr(b),
+                                                      _ptr(c), n_constraints, batch, _ptr(rs),
+                                                      _ptr(proofs_out)),
+                    "zkmi_prove_witness_batch")
 
     def last_timings(self):
         arr = (C.c_double * 8)()

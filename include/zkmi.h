@@ -93,14 +93,20 @@ int zkmi_fixed_base_mul(zkmi_ctx* ctx, int group, const void* base, const void* 
 
 /* -- proving key --------------------------------------------------------------------------- */
 /* Mirrors gnark's groth16 bn254 ProvingKey: Domain, G1{Alpha,Beta,Delta,A,B,Z,K}, G2{Beta,Delta,B},
- * InfinityA/B expressed as the wire index of every retained base. */
+ * InfinityA / InfinityB [UPSTREAM-RECALL, SURVEY.md §3.2].  Which wire each retained base belongs
+ * to can be given either way:
+ *   - gnark's own fields: infinity_a / infinity_b (one byte per wire, Go []bool: 1 = the point is
+ *     at infinity and absent from g1_a / g1_b / g2_b) with a_wire = b_wire = NULL, and n_public
+ *     (pk.G1.K holds wires n_public .. n_wires-1 in order) with k_wire = NULL;
+ *   - or explicit index arrays a_wire / b_wire / k_wire (what this repo's own setup emits).
+ * n_a / n_b / n_k are always the lengths of g1_a / g1_b (= g2_b) / g1_k. */
 typedef struct {
   uint32_t log_n;       /* domain size 2^log_n */
   uint32_t n_wires;     /* columns of the constraint system, including ONE */
   uint32_t n_a, n_b, n_k, n_z;
-  const uint32_t* a_wire; /* n_a: wire index of g1_a[i] (InfinityA filtered out) */
-  const uint32_t* b_wire; /* n_b: wire index of g1_b[i] and g2_b[i] */
-  const uint32_t* k_wire; /* n_k: wire index of g1_k[i] (private wires) */
+  const uint32_t* a_wire; /* n_a: wire index of g1_a[i] (InfinityA filtered out), or NULL */
+  const uint32_t* b_wire; /* n_b: wire index of g1_b[i] and g2_b[i], or NULL */
+  const uint32_t* k_wire; /* n_k: wire index of g1_k[i] (private wires), or NULL */
   const void* g1_a;
   const void* g1_b;
   const void* g1_k;
@@ -113,6 +119,25 @@ typedef struct {
   const void* g2_delta;
   uint32_t window_bits_g1; /* as zkmi_msm_bases_load: 0 = default */
   uint32_t window_bits_g2;
+  /* gnark-shaped alternative to the index arrays (used when the matching *_wire is NULL) */
+  const uint8_t* infinity_a; /* n_wires bytes */
+  const uint8_t* infinity_b; /* n_wires bytes */
+  uint32_t n_public;         /* public wires including ONE */
+  /* -- HBM plan (all optional: 0 = default) -- */
+  /* Largest batch that will be proved with this key.  The auto window plan (window_bits = 0) sizes
+   * the MSM tables so that the prover's working set for max_batch -- two pipeline sets of value
+   * file + a, b, c, the NTT scratch, MSM digits and partial sums -- still fits beside them
+   * (wider batches get narrower tables instead of ZKMI_ERR_OOM at prove time).  0 = 1024. */
+  uint32_t max_batch;
+  /* Upper bound for the key's MSM tables in bytes (G1 + G2), e.g. to leave room for a second key
+   * on the same GPU.  0 = whatever the free HBM minus the working set allows. */
+  uint64_t table_budget_bytes;
+  /* Value slots of the constraint system that will be solved with this key (zkmi_cs_desc.n_slots)
+   * for the working-set estimate; 0 = n_wires + 5 %. */
+  uint32_t n_slots_hint;
+  /* Comb / shared-table MSMs: (window, chunk) blocks in flight as a multiple of the chip's wave
+   * slots (measured best: 16 for comb, 8 for shared tables).  0 = default. */
+  uint32_t msm_chunk_factor;
 } zkmi_pk_desc;
 /* Copies the key to the device and builds the MSM window tables; host buffers may be freed
  * afterwards.  One-off per circuit (gnark's icicle backend does the same lazily). */
@@ -129,7 +154,8 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
  * gnark_crypto_primitives_amd.frontend.compile_circuit. */
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
-  uint32_t n_slots, n_ops, n_consts, _pad;
+  uint32_t n_slots, n_ops, n_consts;
+  uint32_t solve_block; /* lanes per solver workgroup: 64 (default, 0), 128 or 256 */
   const uint32_t* program; /* (n_ops + 1) x 4 words */
   const void* consts;      /* n_consts fr elements, Montgomery */
 } zkmi_cs_desc;
@@ -152,6 +178,21 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
  *   status_out: per proof */
 int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                      size_t batch, const void* rs, void* proofs_out, int32_t* status_out);
+
+/* Groth16 prove from SOLVED witnesses: the entry point for a caller that keeps gnark's own
+ * solver (cs.Solve -> solution.W, solution.A, solution.B, solution.C) and hands quotient, MSMs and
+ * assembly to the GPU -- what gnark's icicle backend does [UPSTREAM-RECALL, SURVEY.md §3.2, §8b].
+ * No zkmi_cs is needed.
+ *   wires: batch x pk.n_wires fr elements (Montgomery, gnark's image), proof-major: the full wire
+ *          vector including the ONE wire at index 0
+ *   a, b, c: batch x n_constraints fr elements each (<L_k,w>, <R_k,w>, <O_k,w>); the library pads
+ *          to the domain
+ *   rs, proofs_out: as zkmi_prove_batch
+ * Blocking; same streams and scratch as zkmi_prove_batch (returns ZKMI_ERR_ARG while submitted
+ * batches are in flight). */
+int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires, const void* a,
+                             const void* b, const void* c, size_t n_constraints, size_t batch,
+                             const void* rs, void* proofs_out);
 
 /* The same prove split in two so that consecutive batches overlap: `submit` stages the inputs and
  * runs the witness solve on a second HIP stream, `collect` runs quotient + MSMs + assembly of the

@@ -1,22 +1,36 @@
 // Package zkmi is the cgo binding of libzkmi.so that a gnark maintainer would add next to
-// backend/groth16/bn254 (see INTEGRATION.md).  SOURCE ONLY: there is no Go toolchain in the build
-// image, this file has never been compiled.  The C-ABI it binds is ../../include/zkmi.h.
+// backend/groth16/bn254 (see INTEGRATION.md).
+//
+// STATUS: SOURCE ONLY, UNBUILT AND UNTESTED.  There is no Go toolchain in the build image, so this
+// file has never been compiled; it documents the binding against include/zkmi.h.  The same C
+// entry points are exercised through ctypes by tests/ (every symbol, on the GPU).
+//
+// Shape: gnark keeps its own frontend, constraint system and solver.  ProveBatch solves each
+// witness with gnark (cs.Solve -> W, A, B, C), hands the solved vectors to
+// zkmi_prove_witness_batch (quotient, five MSMs, assembly on the GPU) and gets gnark Proof values
+// back.  The proving key is described by gnark's own fields (InfinityA / InfinityB, nbPublic), so
+// nothing but a gnark ccs, pk and witnesses is needed.
 package zkmi
 
 /*
 #cgo CFLAGS:  -I${SRCDIR}/../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../gnark_crypto_primitives_amd -lzkmi
+#include <stdlib.h>
 #include "zkmi.h"
 */
 import "C"
 
 import (
 	"errors"
+	"runtime"
 	"sync"
 	"unsafe"
 
 	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
+	"github.com/consensys/gnark/backend"
 	groth16_bn254 "github.com/consensys/gnark/backend/groth16/bn254"
+	"github.com/consensys/gnark/backend/witness"
+	cs_bn254 "github.com/consensys/gnark/constraint/bn254"
 )
 
 // Device owns one zkmi context (one per GPU).  A context is thread-compatible: calls are
@@ -38,54 +52,122 @@ func (d *Device) Close() { C.zkmi_destroy(d.ctx) }
 
 func (d *Device) lastError() error { return errors.New(C.GoString(C.zkmi_last_error(d.ctx))) }
 
-// LoadKey uploads a gnark proving key once.  aWire/bWire list the wire index of every point kept
-// in pk.G1.A / pk.G1.B (the complement of pk.InfinityA / pk.InfinityB); kWire the private wires.
-func (d *Device) LoadKey(pk *groth16_bn254.ProvingKey, aWire, bWire, kWire []uint32) (*C.zkmi_pk, error) {
+// Key is a device-resident proving key (MSM tables built once, like icicle's lazy upload).
+type Key struct {
+	h            *C.zkmi_pk
+	nWires       int
+	nConstraints int
+}
+
+// LoadKey uploads a gnark proving key.  maxBatch sizes the HBM plan (zkmi_pk_desc.max_batch).
+//
+// cgo pointer rules: the descriptor lives in C memory (C.calloc) so that it may hold pointers to
+// Go memory, and every Go slice it points to is pinned for the duration of the call.
+func (d *Device) LoadKey(pk *groth16_bn254.ProvingKey, nbPublic, nbConstraints, maxBatch int) (*Key, error) {
 	logN := 0
 	for n := pk.Domain.Cardinality; n > 1; n >>= 1 {
 		logN++
 	}
-	desc := C.zkmi_pk_desc{
-		log_n: C.uint32_t(logN), n_wires: C.uint32_t(len(pk.InfinityA)),
-		n_a: C.uint32_t(len(pk.G1.A)), n_b: C.uint32_t(len(pk.G1.B)),
-		n_k: C.uint32_t(len(pk.G1.K)), n_z: C.uint32_t(len(pk.G1.Z)),
-		a_wire: (*C.uint32_t)(unsafe.Pointer(&aWire[0])),
-		b_wire: (*C.uint32_t)(unsafe.Pointer(&bWire[0])),
-		k_wire: (*C.uint32_t)(unsafe.Pointer(&kWire[0])),
-		g1_a:   unsafe.Pointer(&pk.G1.A[0]), g1_b: unsafe.Pointer(&pk.G1.B[0]),
-		g1_k:   unsafe.Pointer(&pk.G1.K[0]), g1_z: unsafe.Pointer(&pk.G1.Z[0]),
-		g2_b:   unsafe.Pointer(&pk.G2.B[0]),
-		g1_alpha: unsafe.Pointer(&pk.G1.Alpha), g1_beta: unsafe.Pointer(&pk.G1.Beta),
-		g1_delta: unsafe.Pointer(&pk.G1.Delta),
-		g2_beta:  unsafe.Pointer(&pk.G2.Beta), g2_delta: unsafe.Pointer(&pk.G2.Delta),
-	}
+	infA := boolsToBytes(pk.InfinityA) // Go []bool has no guaranteed C layout: copy to bytes
+	infB := boolsToBytes(pk.InfinityB)
+
+	desc := (*C.zkmi_pk_desc)(C.calloc(1, C.size_t(unsafe.Sizeof(C.zkmi_pk_desc{}))))
+	defer C.free(unsafe.Pointer(desc))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	p := func(x unsafe.Pointer) unsafe.Pointer { pin.Pin(x); return x }
+
+	desc.log_n = C.uint32_t(logN)
+	desc.n_wires = C.uint32_t(len(pk.InfinityA))
+	desc.n_a, desc.n_b = C.uint32_t(len(pk.G1.A)), C.uint32_t(len(pk.G1.B))
+	desc.n_k, desc.n_z = C.uint32_t(len(pk.G1.K)), C.uint32_t(len(pk.G1.Z))
+	desc.g1_a, desc.g1_b = p(unsafe.Pointer(&pk.G1.A[0])), p(unsafe.Pointer(&pk.G1.B[0]))
+	desc.g1_k, desc.g1_z = p(unsafe.Pointer(&pk.G1.K[0])), p(unsafe.Pointer(&pk.G1.Z[0]))
+	desc.g2_b = p(unsafe.Pointer(&pk.G2.B[0]))
+	desc.g1_alpha, desc.g1_beta = p(unsafe.Pointer(&pk.G1.Alpha)), p(unsafe.Pointer(&pk.G1.Beta))
+	desc.g1_delta = p(unsafe.Pointer(&pk.G1.Delta))
+	desc.g2_beta, desc.g2_delta = p(unsafe.Pointer(&pk.G2.Beta)), p(unsafe.Pointer(&pk.G2.Delta))
+	// a_wire = b_wire = k_wire = NULL: the library derives them from gnark's own fields
+	desc.infinity_a = (*C.uint8_t)(p(unsafe.Pointer(&infA[0])))
+	desc.infinity_b = (*C.uint8_t)(p(unsafe.Pointer(&infB[0])))
+	desc.n_public = C.uint32_t(nbPublic)
+	desc.max_batch = C.uint32_t(maxBatch)
+
 	d.mu.Lock()
 	defer d.mu.Unlock()
 	var h *C.zkmi_pk
-	if rc := C.zkmi_pk_load(d.ctx, &desc, &h); rc != 0 {
+	if rc := C.zkmi_pk_load(d.ctx, desc, &h); rc != 0 {
 		return nil, d.lastError()
 	}
-	return h, nil
+	return &Key{h: h, nWires: len(pk.InfinityA), nConstraints: nbConstraints}, nil
 }
 
-// ProveBatch is groth16.Prove for `batch` independent witnesses of one circuit.  inputs holds the
-// public then secret assignments of each witness back to back; rs the two blinding scalars gnark
-// would sample inside Prove, per proof.  status[i] == -5: witness i does not satisfy the circuit.
-func (d *Device) ProveBatch(pk *C.zkmi_pk, cs *C.zkmi_cs, inputs []fr.Element, batch int,
-	rs []fr.Element, proofs []groth16_bn254.Proof) ([]int32, error) {
+func boolsToBytes(b []bool) []byte {
+	out := make([]byte, len(b))
+	for i, v := range b {
+		if v {
+			out[i] = 1
+		}
+	}
+	return out
+}
+
+// ProveBatch is groth16.Prove(ccs, pk, w) for a batch of independent witnesses of one circuit:
+// gnark's solver on the CPU (it can run in goroutines, one per witness), everything else on the
+// GPU.  rs holds the two blinding scalars per proof that gnark samples inside Prove.
+func (d *Device) ProveBatch(ccs *cs_bn254.R1CS, key *Key, ws []witness.Witness, rs []fr.Element,
+	opts ...backend.ProverOption) ([]groth16_bn254.Proof, error) {
+	batch := len(ws)
+	if len(rs) != 2*batch {
+		return nil, errors.New("rs must hold 2 scalars per proof")
+	}
+	popt, err := backend.NewProverConfig(opts...)
+	if err != nil {
+		return nil, err
+	}
+	nw, nc := key.nWires, key.nConstraints
+	wires := make([]fr.Element, batch*nw)
+	a := make([]fr.Element, batch*nc)
+	b := make([]fr.Element, batch*nc)
+	c := make([]fr.Element, batch*nc)
+	var wg sync.WaitGroup
+	errs := make([]error, batch)
+	for i := range ws {
+		wg.Add(1)
+		go func(i int) {
+			defer wg.Done()
+			sol, err := ccs.Solve(ws[i], popt.SolverOpts...) // gnark's own solver
+			if err != nil {
+				errs[i] = err
+				return
+			}
+			s := sol.(*cs_bn254.R1CSSolution)
+			copy(wires[i*nw:], s.W)
+			copy(a[i*nc:], s.A[:nc])
+			copy(b[i*nc:], s.B[:nc])
+			copy(c[i*nc:], s.C[:nc])
+		}(i)
+	}
+	wg.Wait()
+	for _, e := range errs {
+		if e != nil {
+			return nil, e
+		}
+	}
 	raw := make([]byte, 256*batch) // Ar | Krs | Bs, the field order of gnark's Proof
-	status := make([]int32, batch)
 	d.mu.Lock()
-	rc := C.zkmi_prove_batch(d.ctx, pk, cs, unsafe.Pointer(&inputs[0]), C.size_t(batch),
-		unsafe.Pointer(&rs[0]), unsafe.Pointer(&raw[0]), (*C.int32_t)(unsafe.Pointer(&status[0])))
+	rc := C.zkmi_prove_witness_batch(d.ctx, key.h, unsafe.Pointer(&wires[0]), unsafe.Pointer(&a[0]),
+		unsafe.Pointer(&b[0]), unsafe.Pointer(&c[0]), C.size_t(nc), C.size_t(batch),
+		unsafe.Pointer(&rs[0]), unsafe.Pointer(&raw[0]))
 	d.mu.Unlock()
 	if rc != 0 {
 		return nil, d.lastError()
 	}
-	for i := range proofs {
+	proofs := make([]groth16_bn254.Proof, batch)
+	for i := range proofs { // G1Affine / G2Affine share the memory image of the 256-byte record
 		copy(unsafe.Slice((*byte)(unsafe.Pointer(&proofs[i].Ar)), 64), raw[256*i:])
 		copy(unsafe.Slice((*byte)(unsafe.Pointer(&proofs[i].Krs)), 64), raw[256*i+64:])
 		copy(unsafe.Slice((*byte)(unsafe.Pointer(&proofs[i].Bs)), 128), raw[256*i+128:])
 	}
-	return status, nil
+	return proofs, nil
 }

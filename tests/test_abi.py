@@ -25,9 +25,27 @@ def test_header_symbols_are_exported_and_bound():
     assert bound <= set(names)
 
 
-def test_struct_layouts_match_header():
-    assert C.sizeof(lib.PkDesc) == 6 * 4 + 13 * 8 + 2 * 4
-    assert C.sizeof(lib.CsDesc) == 8 * 4 + 2 * 8
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of the descriptor structs as a C compiler lays out include/zkmi.h, against
+    the ctypes mirrors in lib.py (what a cgo caller would see too)."""
+    import subprocess
+    fields = {"zkmi_pk_desc": [n for n, _ in lib.PkDesc._fields_],
+              "zkmi_cs_desc": [n for n, _ in lib.CsDesc._fields_]}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "zkmi.h"', 'int main(void) {']
+    for st, fs in fields.items():
+        prog.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            prog.append(f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    prog += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("zkmi_pk_desc", lib.PkDesc), ("zkmi_cs_desc", lib.CsDesc)):
+        assert int(out[st]) == C.sizeof(cls), st
+        for f in fields[st]:
+            assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
 
 
 def test_no_cpu_fallback_without_gpu():

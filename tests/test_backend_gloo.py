@@ -53,9 +53,20 @@ def _worker(rank, world, port, q):
         proofs, status = backend.prove_sharded(prover, inp, rs)
         want, wstatus = prover(inp, rs)
         ok = wstatus == 0
-        q.put((rank, bool(np.array_equal(status != 0, wstatus != 0)
-                          and np.array_equal(proofs[ok], want[ok])
-                          and list(wstatus != 0) == [False] * 4 + [True])))
+        good = bool(np.array_equal(status != 0, wstatus != 0)
+                    and np.array_equal(proofs[ok], want[ok])
+                    and list(wstatus != 0) == [False] * 4 + [True])
+        # the form bench.py uses: this rank's shard as torch tensors (as zkmi_prove_collect leaves
+        # them), gathered without a numpy round trip -- strong scaling: the global batch is split
+        import torch
+        lo, hi = backend.shard_range(batch, rank, world)
+        tp = torch.from_numpy(want[lo:hi].view(np.int64).copy())
+        ts = torch.from_numpy(wstatus[lo:hi].astype(np.int32))
+        gp, gs = backend.gather_proofs(tp, ts, batch)
+        good = good and isinstance(gp, torch.Tensor) and gp.shape == (batch, 32) \
+            and np.array_equal(gp.numpy().view(np.uint64), want) \
+            and np.array_equal(gs.numpy(), wstatus)
+        q.put((rank, good))
     finally:
         dist.destroy_process_group()
 
@@ -75,3 +86,24 @@ def test_prove_sharded_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gather_proofs_forced_single_rank():
+    """world = 1 with force=True still runs the collective (what tools/nccl_selftest.py does over
+    RCCL on the GPU box)."""
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        p = np.arange(7 * 32, dtype=np.uint64).reshape(7, 32)
+        st = np.array([0, -5, 0, 0, 0, 0, -5], dtype=np.int32)
+        gp, gs = backend.gather_proofs(p, st, 7, force=True)
+        assert np.array_equal(gp, p) and np.array_equal(gs, st)
+        tp, ts = backend.gather_proofs(torch.from_numpy(p.view(np.int64)), torch.from_numpy(st), 7,
+                                       force=True)
+        assert np.array_equal(tp.numpy().view(np.uint64), p) and np.array_equal(ts.numpy(), st)
+    finally:
+        dist.destroy_process_group()

@@ -328,3 +328,77 @@ def test_degenerate_circuits(zk_ctx, wbits):
     status = _prove_and_check(zk_ctx, cc, [{"X": 4, "Y": 16}, {"X": H.R - 1, "Y": 1},
                                            {"X": 2, "Y": 5}], 22, wbits)
     assert list(status != 0) == [False, False, True]
+
+
+def test_prove_witness_batch_matches_oracle(zk_ctx):
+    """zkmi_prove_witness_batch (the entry for a caller that keeps gnark's own solver): fed with
+    the C oracle's solved (W, a, b, c) it yields the oracle's proofs -- and the proofs of
+    zkmi_prove_batch on the same inputs.  The key is described the way gnark's ProvingKey is
+    (InfinityA / InfinityB byte maps + nbPublic), under per-window, shared and comb plans."""
+    from oracle import cref
+    cc = compile_circuit(circuits.smt_inclusion_circuit(10))
+    pk, vk, td = groth16.setup(cc, 41, groth16.gpu_mul(zk_ctx))
+    rng = random.Random(41)
+    batch = 70
+    ws = [smt_witness.synthetic_inclusion(rng, 10, 4) for _ in range(batch)]
+    inp = np.stack([to_mont_array(cc.assignment_vector(w)) for w in ws])
+    rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in range(batch)])
+    rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
+    solved = [cref.r1cs_solve(rh, inp[i]) for i in range(batch)]
+    assert all(s[0] == 0 for s in solved)
+    W = np.stack([s[1] for s in solved])
+    A, B, Cc = (np.stack([s[k] for s in solved]) for k in (2, 3, 4))
+    assert W.shape == (batch, cc.n_wires, 4) and A.shape == (batch, cc.n_constraints, 4)
+    want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp, rs)
+    assert not wstatus.any()
+    for wbits in ((7, 5), (108, 106), (0, 0), (209, 208)):
+        prover = groth16.Prover(zk_ctx, cc, pk, *wbits, gnark_key_layout=True)
+        got = prover.prove_witness(W, A, B, Cc, rs)
+        assert np.array_equal(got, want), wbits
+        full, status = prover.prove(inp, rs)
+        assert not status.any() and np.array_equal(full, want)
+        with pytest.raises(ValueError):
+            prover.prove_witness(W[:, :-1], A, B, Cc, rs)       # wrong wire count
+        prover.close()
+
+
+def test_pk_plan_respects_budget_and_batch(zk_ctx):
+    """zkmi_pk_desc.table_budget_bytes caps the auto plan's tables; two keys live on one context;
+    a key whose infinity maps disagree with its point counts is refused."""
+    from gnark_crypto_primitives_amd import lib
+    from oracle import cref
+    cc = compile_circuit(circuits.smt_inclusion_circuit(24))
+    pk, _, _ = groth16.setup(cc, 42, groth16.gpu_mul(zk_ctx))
+    rng = random.Random(42)
+    ws = [smt_witness.synthetic_inclusion(rng, 24, 5) for _ in range(5)]
+    inp = np.stack([to_mont_array(cc.assignment_vector(w)) for w in ws])
+    rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in ws])
+    want, _, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk), inp, rs)
+    provers = []
+    for budget in (1 << 28, 1 << 31):
+        p = groth16.Prover(zk_ctx, cc, pk, 0, 0, table_budget_bytes=budget, max_batch=256,
+                           msm_chunk_factor=4, solve_block=128)
+        info = zk_ctx.pk_info(p.pk_h)
+        assert info["g1_table_bytes"] + info["g2_table_bytes"] <= budget, (budget, info)
+        provers.append((p, info))
+    assert provers[1][1]["g1_table_bytes"] > provers[0][1]["g1_table_bytes"]
+    for p, _ in provers:                       # both keys resident at once
+        proofs, status = p.prove(inp, rs)
+        assert not status.any() and np.array_equal(proofs, want)
+    for p, _ in provers:
+        p.close()
+    bad = groth16.ProvingKey()
+    bad.__dict__.update(pk.__dict__)
+    bad.a_wire = pk.a_wire[:-1]                # one retained wire fewer than points in g1_a
+    with pytest.raises(lib.ZkmiError):
+        class _P(groth16.Prover):
+            pass
+        k = groth16.Prover.__new__(groth16.Prover)
+        inf_a, inf_b = bad.infinity_maps()
+        keep = [np.ascontiguousarray(x) for x in (pk.g1_a, pk.g1_b, pk.g1_k, pk.g1_z, pk.g2_b,
+                                                  pk.g1_alpha, pk.g1_beta, pk.g1_delta,
+                                                  pk.g2_beta, pk.g2_delta)]
+        pd = lib.PkDesc(pk.log_n, pk.n_wires, len(pk.a_wire), len(pk.b_wire), len(pk.k_wire),
+                        pk.g1_z.shape[0], None, None, None, *[x.ctypes.data for x in keep], 7, 5,
+                        inf_a.ctypes.data, inf_b.ctypes.data, cc.n_public, 0, 0, 0, 0)
+        zk_ctx.pk_load(pd)

@@ -117,6 +117,33 @@ __global__ void k_fma_f64(uint64_t* out, uint32_t a, uint32_t b, int iters) {
       (uint64_t)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);
 }
 
+// signed variant, and dependent chains (all 8 instructions of a group on one / two accumulators):
+// what a single-accumulator Montgomery column chain looks like to the SIMD
+#define KMAD(NAME, OP, R0, R1, R2, R3, R4, R5, R6, R7)                                          \
+  __global__ void NAME(uint64_t* out, uint32_t a, uint32_t b, int iters) {                     \
+    uint64_t r0 = threadIdx.x, r1 = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, r6 = 6, r7 = 7;         \
+    uint32_t x = a + threadIdx.x, y = b;                                                       \
+    for (int i = 0; i < iters; i++) {                                                          \
+      REP8(asm volatile(OP " %" #R0 ", vcc, %8, %9, %" #R0 "\n\t" OP " %" #R1 ", vcc, %8, %9, %" #R1 "\n\t" \
+                        OP " %" #R2 ", vcc, %8, %9, %" #R2 "\n\t" OP " %" #R3 ", vcc, %8, %9, %" #R3 "\n\t" \
+                        OP " %" #R4 ", vcc, %8, %9, %" #R4 "\n\t" OP " %" #R5 ", vcc, %8, %9, %" #R5 "\n\t" \
+                        OP " %" #R6 ", vcc, %8, %9, %" #R6 "\n\t" OP " %" #R7 ", vcc, %8, %9, %" #R7 "\n\t" \
+                        : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), \
+                          "+v"(r7)                                                             \
+                        : "v"(x), "v"(y)                                                       \
+                        : "vcc");)                                                             \
+    }                                                                                          \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;        \
+  }
+KMAD(k_mad_i64, "v_mad_i64_i32", 0, 1, 2, 3, 4, 5, 6, 7)
+KMAD(k_mad_i64_dep1, "v_mad_i64_i32", 0, 0, 0, 0, 0, 0, 0, 0)
+KMAD(k_mad_i64_dep2, "v_mad_i64_i32", 0, 1, 0, 1, 0, 1, 0, 1)
+KMAD(k_mad_u64_dep1, "v_mad_u64_u32", 0, 0, 0, 0, 0, 0, 0, 0)
+K64(k_ashr_i64,
+    "v_ashrrev_i64 %0, 1, %0\n\tv_ashrrev_i64 %1, 1, %1\n\tv_ashrrev_i64 %2, 1, %2\n\t"
+    "v_ashrrev_i64 %3, 1, %3\n\tv_ashrrev_i64 %4, 1, %4\n\tv_ashrrev_i64 %5, 1, %5\n\t"
+    "v_ashrrev_i64 %6, 1, %6\n\tv_ashrrev_i64 %7, 1, %7\n\t")
+
 template <class K>
 static void run(const char* name, K kern, int waves_per_simd) {
   const int iters = 2000;
@@ -145,6 +172,11 @@ static void run(const char* name, K kern, int waves_per_simd) {
 int main() {
   for (int w : {1, 2, 4}) {
     run("v_mad_u64_u32", k_mad_u64, w);
+    run("v_mad_i64_i32", k_mad_i64, w);
+    run("v_mad_i64 1 chain", k_mad_i64_dep1, w);
+    run("v_mad_i64 2 chains", k_mad_i64_dep2, w);
+    run("v_mad_u64 1 chain", k_mad_u64_dep1, w);
+    run("v_ashrrev_i64", k_ashr_i64, w);
     run("v_mul_lo_u32", k_mul_lo, w);
     run("v_mul_hi_u32", k_mul_hi, w);
     run("v_add_u32", k_add_u32, w);
