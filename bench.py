@@ -110,7 +110,7 @@ def main():
                     help="skip the per-step all_gather of proof records (N > 1)")
     ap.add_argument("--worst-case-steps", type=int, default=-1,
                     help="arbo only: extra timed steps on witnesses with every level populated "
-                         "(every wire differs between lanes); -1: steps / 4, 0: skip")
+                         "(every wire differs between lanes); -1: as many as --steps, 0: skip")
     ap.add_argument("--gen-workers", type=int, default=0, help="witness generator processes")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one blocking zkmi_prove_batch per step (no overlap of consecutive steps)")
@@ -127,7 +127,8 @@ def main():
     t0 = time.time()
     circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
     cc = compile_circuit(circuit)
-    log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops "
+    log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops in "
+        f"{cc.v_n_steps} steps x {cc.lanes_per_proof} lanes "
         f"({time.time() - t0:.1f}s)")
 
     # ---- synthetic witnesses, seeded per rank, generated by worker processes
@@ -138,7 +139,7 @@ def main():
     else:
         B, global_batch = args.batch, args.batch * world
     n_distinct = min(B, args.distinct) if args.distinct > 0 else B
-    wc_steps = args.worst_case_steps if args.worst_case_steps >= 0 else max(args.steps // 4, 2)
+    wc_steps = args.worst_case_steps if args.worst_case_steps >= 0 else args.steps
     if args.workload != "arbo" or args.populated >= args.levels - 1:
         wc_steps = 0
     jobs = [("main", 1000 + rank, n_distinct, args.populated)]
@@ -167,17 +168,26 @@ def main():
     if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    if pg:
-        # first collective now: RCCL's buffers are allocated before the MSM tables size themselves
-        # against the free HBM
-        t = torch.zeros(1, dtype=torch.float64, device=cdev)
-        dist.all_reduce(t)
-        if cdev.type == "cuda":
-            torch.cuda.synchronize()
+        # RCCL prints a version banner on stdout at its first collective; stdout must carry the one
+        # JSON line only, so fd 1 points at stderr until the group is up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            # first collective now: RCCL's buffers are allocated before the MSM tables size
+            # themselves against the free HBM
+            t = torch.zeros(1, dtype=torch.float64, device=cdev)
+            dist.all_reduce(t)
+            if cdev.type == "cuda":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     ctx = lib.Context(local_rank)
     pk, vk, _ = groth16.setup(cc, 2, groth16.gpu_mul(ctx))

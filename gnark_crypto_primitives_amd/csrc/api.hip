@@ -420,7 +420,7 @@ static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size
     if (rc != ZKMI_ERR_OOM || !may_relax) return rc;
     if (plan.comb) {
       if (plan.comb <= 8) return rc;
-      plan = plan_comb(plan.comb - 1);
+      plan = plan_comb(plan.comb - 1, plan.comb_signed != 0);
     } else if (plan.shared) {
       if (plan.bits[0] <= 4) return rc;
       plan = plan_shared(plan.bits[0] - 1);
@@ -433,12 +433,17 @@ static int bases_load_plan(zkmi_ctx* ctx, int group, const void* bases_dev, size
 
 // explicit window_bits of the C-ABI: 2..16 = per-window tables, uniform width; 100 + c = one
 // shared table of c-bit signed digits per base (c in 4..16)
-// 200 + k = comb tables over groups of k bases (k in 2..20)
+// 200 + k = comb tables over groups of k bases (k in 2..20); 300 + k = sign-pattern comb tables
+// (k in 3..21: 2^(k-1) entries per group, the auto plan's choice)
 static bool window_bits_ok(int wb) {
-  return wb == 0 || (wb >= 2 && wb <= 16) || (wb >= 104 && wb <= 116) || (wb >= 202 && wb <= 220);
+  return wb == 0 || (wb >= 2 && wb <= 16) || (wb >= 104 && wb <= 116) ||
+         (wb >= 202 && wb <= 220) || (wb >= 303 && wb <= 321);
 }
 static WinPlan plan_explicit(int wb) {
-  return wb >= 200 ? plan_comb(wb - 200) : wb >= 100 ? plan_shared(wb - 100) : plan_uniform(wb);
+  return wb >= 300   ? plan_comb(wb - 300, true)
+         : wb >= 200 ? plan_comb(wb - 200, false)
+         : wb >= 100 ? plan_shared(wb - 100)
+                     : plan_uniform(wb);
 }
 static const int COMB_WINDOWS = 254;
 // HBM the prover needs beside the tables to prove batches of up to `max_batch` with a key of this
@@ -474,7 +479,7 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
   ZK_HIP(hipSetDevice(ctx->device));
   if (!out) return ZKMI_ERR_ARG;
   if (!window_bits_ok(window_bits)) {
-    ctx->err = "window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
+    ctx->err = "window_bits must be 0 (auto), in [2,16], 100 + [4,16], 200 + [2,20] or 300 + [3,21]";
     return ZKMI_ERR_ARG;
   }
   Staged sb(ctx);
@@ -494,9 +499,10 @@ int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, i
     if (ps.W < plan.W) plan = ps;
     if (n >= 64) {
       int k1, k2;
-      plan_comb_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable, &k1, &k2);
+      bool s1, s2;
+      plan_comb_for_budget(group == 1 ? n : 0, group == 2 ? n : 0, 0.9 * usable, &k1, &k2, &s1, &s2);
       const int k = group == 1 ? k1 : k2;
-      if ((double)COMB_WINDOWS / k < (double)plan.W) plan = plan_comb(k);
+      if ((double)COMB_WINDOWS / k < (double)plan.W) plan = plan_comb(k, group == 1 ? s1 : s2);
     }
   }
   return bases_load_plan(ctx, group, sb.dev, n, plan, window_bits == 0, out);
@@ -679,7 +685,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
         }
   }
   if (!window_bits_ok((int)d->window_bits_g1) || !window_bits_ok((int)d->window_bits_g2)) {
-    ctx->err = "pk: window_bits must be 0 (auto), in [2,16], 100 + [4,16] or 200 + [2,20]";
+    ctx->err = "pk: window_bits must be 0 (auto), in [2,16], 100 + [4,16], 200 + [2,20] or 300 + [3,21]";
     return ZKMI_ERR_ARG;
   }
   if (d->msm_chunk_factor > 64) {
@@ -721,9 +727,10 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   // keys keep the layouts above (their MSMs are latency, not throughput)
   if (n1 >= 4096) {
     int k1 = 0, k2 = 0;
-    plan_comb_for_budget(auto1 ? n1 : 0, auto2 ? d->n_b : 0, 0.98 * usable, &k1, &k2);
-    if (auto1 && (double)COMB_WINDOWS / k1 < (double)p1.W) p1 = plan_comb(k1);
-    if (auto2 && (double)COMB_WINDOWS / k2 < (double)p2.W) p2 = plan_comb(k2);
+    bool s1 = true, s2 = true;
+    plan_comb_for_budget(auto1 ? n1 : 0, auto2 ? d->n_b : 0, 0.98 * usable, &k1, &k2, &s1, &s2);
+    if (auto1 && (double)COMB_WINDOWS / k1 < (double)p1.W) p1 = plan_comb(k1, s1);
+    if (auto2 && (double)COMB_WINDOWS / k2 < (double)p2.W) p2 = plan_comb(k2, s2);
   }
   auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
                   zkmi_msm_bases** out) -> int {
@@ -789,59 +796,102 @@ void zkmi_cs_free(zkmi_ctx* ctx, zkmi_cs* cs) {
 int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   ZK_HIP(hipSetDevice(ctx->device));
   if (!d || !out) return ZKMI_ERR_ARG;
-  // validate every slot / constant index on the host before anything reaches a kernel
+  const uint32_t S = d->lanes_per_proof;
+  if (S != 1 && S != 2 && S != 4 && S != 8 && S != 16) {
+    ctx->err = "cs: lanes_per_proof must be 1, 2, 4, 8 or 16";
+    return ZKMI_ERR_ARG;
+  }
+  // validate every slot / constant / row index on the host before anything reaches a kernel
+  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV };
   const uint32_t* p = d->program;
+  const size_t stride = (size_t)(1 + S) * 4;
+  std::vector<uint8_t> row_seen(d->n_constraints, 0);
   uint32_t n_abc = 0;
-  for (uint32_t i = 0; i < d->n_ops; i++) {
-    const uint32_t op = p[4 * i] & 0xff, dst = p[4 * i + 1], a = p[4 * i + 2], b = p[4 * i + 3];
-    bool ok = true;
-    switch (op) {
-      case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV:
-        ok = dst < d->n_slots && a < d->n_slots && b < d->n_slots;
-        break;
-      case OP_MULC: case OP_ADDC:
-        ok = dst < d->n_slots && a < d->n_slots && b < d->n_consts;
-        break;
-      case OP_NEG: case OP_INV: case OP_COPY:
-        ok = dst < d->n_slots && a < d->n_slots;
-        break;
-      case OP_SETC:
-        ok = dst < d->n_slots && b < d->n_consts;
-        break;
-      case OP_BITS:
-        ok = a < d->n_slots && b <= 256 && (uint64_t)dst + b <= d->n_slots;
-        break;
-      case OP_ABC: case OP_MULABC: case OP_XORABC:
-        ok = dst < d->n_slots && a < d->n_slots && b < d->n_slots;
-        n_abc++;
-        break;
-      case OP_BATCHINV: {
-        // dst = number of (OP_PAIR, dst, src) rows that follow; distinct wire slots on both sides
-        ok = (uint64_t)i + dst < d->n_ops;
-        for (uint32_t k = 1; ok && k <= dst; k++) {
-          const uint32_t* q = p + 4 * (size_t)(i + k);
-          ok = (q[0] & 0xff) == OP_PAIR && q[1] < d->n_wires && q[2] < d->n_wires && q[1] != q[2];
-          for (uint32_t k2 = 1; ok && k2 <= dst; k2++)
-            ok = q[1] != p[4 * (size_t)(i + k2) + 2];   // no dst aliases any src
-        }
-        if (ok) i += dst;
-        break;
+  auto bad = [&](uint32_t r) {
+    ctx->err = "cs: malformed program row " + std::to_string(r);
+    return ZKMI_ERR_ARG;
+  };
+  for (uint32_t r = 0; r < d->n_rows; r++) {
+    const uint32_t* h = p + r * stride;
+    const uint32_t cls = h[0] & 0xff;
+    if (h[0] & 0x100) return bad(r);   // a pair row outside a BATCHINV step
+    if (cls == CLS_BINV) {
+      const uint32_t npairs = h[1], nrows = h[2];
+      if ((uint64_t)r + nrows >= (uint64_t)d->n_rows + 0 && nrows) {
+        if ((uint64_t)r + nrows > d->n_rows - 1) return bad(r);
       }
-      default:
-        ok = false;
+      if (nrows != (npairs + S - 1) / S) return bad(r);
+      std::vector<uint32_t> dsts, srcs;
+      for (uint32_t t = 1; t <= nrows; t++) {
+        const uint32_t* hh = p + (size_t)(r + t) * stride;
+        if (hh[0] != (CLS_BINV | 0x100u)) return bad(r + t);
+        for (uint32_t l = 0; l < S; l++) {
+          const uint32_t* q = hh + 4 * (1 + l);
+          if ((q[0] & 0x1f) == OP_END) continue;
+          if ((q[0] & 0x1f) != OP_PAIR || q[1] >= d->n_wires || q[2] >= d->n_wires || q[1] == q[2])
+            return bad(r + t);
+          dsts.push_back(q[1]);
+          srcs.push_back(q[2]);
+        }
+      }
+      if (dsts.size() != npairs) return bad(r);
+      std::sort(srcs.begin(), srcs.end());
+      for (uint32_t x : dsts)   // no dst aliases any src (dst rows are the prefix scratch)
+        if (std::binary_search(srcs.begin(), srcs.end(), x)) return bad(r);
+      r += nrows;
+      continue;
     }
-    if (!ok) {
-      ctx->err = "cs: malformed instruction at " + std::to_string(i);
-      return ZKMI_ERR_ARG;
+    if (cls < CLS_M || cls > CLS_BITS) return bad(r);
+    for (uint32_t l = 0; l < S; l++) {
+      const uint32_t* q = h + 4 * (1 + l);
+      const uint32_t op = q[0] & 0x1f, k = q[0] >> 8, dst = q[1], a = q[2], b = q[3];
+      if (op == OP_END) continue;
+      bool ok = false, emits = false;
+      switch (cls) {
+        case CLS_M:
+          emits = op == OP_MULABC;
+          ok = (op == OP_MUL || op == OP_MULABC) ? (dst < d->n_slots && a < d->n_slots && b < d->n_slots)
+               : op == OP_MULC                   ? (dst < d->n_slots && a < d->n_slots && b < d->n_consts)
+                                                 : false;
+          break;
+        case CLS_X:
+          emits = op == OP_XORABC;
+          ok = (op == OP_XORABC || op == OP_XOR) && dst < d->n_slots && a < d->n_slots &&
+               b < d->n_slots;
+          break;
+        case CLS_A:
+          ok = (op == OP_ADD || op == OP_SUB) ? (dst < d->n_slots && a < d->n_slots && b < d->n_slots)
+               : op == OP_ADDC                ? (dst < d->n_slots && a < d->n_slots && b < d->n_consts)
+               : (op == OP_NEG || op == OP_COPY) ? (dst < d->n_slots && a < d->n_slots)
+               : op == OP_SETC                   ? (dst < d->n_slots && b < d->n_consts)
+                                                 : false;
+          break;
+        case CLS_R:
+          emits = true;
+          ok = op == OP_ABC && dst < d->n_slots && a < d->n_slots && b < d->n_slots;
+          break;
+        case CLS_I:
+          ok = op == OP_INV   ? (dst < d->n_slots && a < d->n_slots)
+               : op == OP_DIV ? (dst < d->n_slots && a < d->n_slots && b < d->n_slots)
+                              : false;
+          break;
+        case CLS_BITS:
+          ok = l == 0 && op == OP_BITS && a < d->n_slots && b <= 256 && (uint64_t)dst + b <= d->n_slots;
+          break;
+      }
+      if (ok && emits) {
+        ok = k < d->n_constraints && !row_seen[k];
+        if (ok) {
+          row_seen[k] = 1;
+          n_abc++;
+        }
+      }
+      if (!ok) return bad(r);
     }
   }
   if (n_abc != d->n_constraints) {
     ctx->err = "cs: program emits " + std::to_string(n_abc) + " constraint rows, expected " +
                std::to_string(d->n_constraints);
-    return ZKMI_ERR_ARG;
-  }
-  if (d->solve_block != 0 && d->solve_block != 64 && d->solve_block != 128 && d->solve_block != 256) {
-    ctx->err = "cs: solve_block must be 0, 64, 128 or 256";
     return ZKMI_ERR_ARG;
   }
   auto* cs = new zkmi_cs();
@@ -850,10 +900,10 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   cs->n_secret = d->n_secret;
   cs->n_constraints = d->n_constraints;
   cs->n_slots = d->n_slots;
-  cs->n_ops = d->n_ops;
+  cs->n_rows = d->n_rows;
   cs->n_consts = d->n_consts;
-  cs->solve_block = d->solve_block;
-  int rc = upload_u32(ctx, d->program, (size_t)(d->n_ops + 1) * 4, &cs->program);
+  cs->lanes_per_proof = S;
+  int rc = upload_u32(ctx, d->program, (size_t)d->n_rows * stride, &cs->program);
   if (rc) {
     delete cs;
     return rc;
@@ -1134,18 +1184,20 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
     bool same = true;   // an out-of-memory relaxation may have narrowed one table
     for (int i = 0; i < 3; i++)
       same = same && ms[i]->plan.bits[0] == pk->Z->plan.bits[0] &&
-             ms[i]->plan.comb == pk->Z->plan.comb;
+             ms[i]->plan.comb == pk->Z->plan.comb &&
+             ms[i]->plan.comb_signed == pk->Z->plan.comb_signed;
     if (same) {
-      if ((rc = msm_horner_run(ctx, q3, 1, pk->Z->plan, 4, ws, os, Bp))) return rc;
+      if ((rc = msm_horner_run(ctx, q3, 4, ms, ws, os, Bp))) return rc;
     } else {
       for (int i = 0; i < 4; i++)
-        if ((rc = msm_horner_run(ctx, q3, 1, ms[i]->plan, 1, ws + i, os + i, Bp))) return rc;
+        if ((rc = msm_horner_run(ctx, q3, 1, ms + i, ws + i, os + i, Bp))) return rc;
     }
   }
   if (pk->B2->plan.shared || pk->B2->plan.comb) {
     void* ws[1] = {v.w2};
     void* os[1] = {v.sB2};
-    if ((rc = msm_horner_run(ctx, q3, 2, pk->B2->plan, 1, ws, os, Bp))) return rc;
+    const zkmi_msm_bases* ms[1] = {pk->B2};
+    if ((rc = msm_horner_run(ctx, q3, 1, ms, ws, os, Bp))) return rc;
   }
   PkConsts pc{pk->alpha, pk->beta1, pk->beta2};
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, q3, v.sA, v.sB1, v.sK,

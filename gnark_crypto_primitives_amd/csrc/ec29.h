@@ -113,21 +113,13 @@ ZK_HD void madd29(G1Acc29& acc, const Fq29& qx, const Fq29& qy) {
 }
 
 // ---- G2 (Fq2 components, lazy reduction) -------------------------------------------------------
-// ff29.h's Fq2 product and square.  The G2 kernels run two waves per SIMD, so on the device the two
-// components (independent products) are interleaved in one asm block with two accumulator chains.
-#if defined(__HIP_DEVICE_COMPILE__)
+// ff29.h's Fq2 product and square on the products above
 ZK_HD Fq2_29 mmul(const Fq2_29& a, const Fq2_29& b) {
-  const auto r = mul_add2_x2_asm(a.c0, b.c0, neg(a.c1), b.c1, a.c1);
-  return {r.lo, r.hi};
+  return {mmul_add2(a.c0, b.c0, neg(a.c1), b.c1), mmul_add2(a.c0, b.c1, a.c1, b.c0)};
 }
 ZK_HD Fq2_29 msqr(const Fq2_29& a) {
-  const auto r = mul_x2_asm(add(a.c0, a.c1), sub(a.c0, a.c1), add(a.c0, a.c0), a.c1);
-  return {r.lo, r.hi};
+  return {mmul(add(a.c0, a.c1), sub(a.c0, a.c1)), mmul(add(a.c0, a.c0), a.c1)};
 }
-#else
-ZK_HD Fq2_29 mmul(const Fq2_29& a, const Fq2_29& b) { return mul(a, b); }
-ZK_HD Fq2_29 msqr(const Fq2_29& a) { return sqr(a); }
-#endif
 
 // Invariants between calls: x, y weakly reduced (|component| < 0.6p); zz, zzz products.
 struct G2Acc29 {

@@ -30,6 +30,13 @@
 #include "zkmi_internal.h"
 #include "ec29.h"
 
+// This file is compiled twice (Makefile): ZK_MSM_PART 1 = plans, dispatch and the G1 (Fq) kernels,
+// ZK_MSM_PART 2 = the G2 (Fq2) instantiations of the table-build and accumulate paths only -- the
+// two halves compile in parallel (each is several minutes of hipcc).
+#ifndef ZK_MSM_PART
+#define ZK_MSM_PART 1
+#endif
+
 namespace zk {
 
 ZK_HD Fq to_r261_domain(const Fq& x) {
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 // Signed digits without a carry chain: with K = sum_j 2^(pos_j + c_j - 1) and s' = s + K, digit j
 // is ((s' >> pos_j) & (2^c_j - 1)) - 2^(c_j - 1), each in [-2^(c_j-1), 2^(c_j-1)).  One pass
 // converts the Montgomery scalars to integers and stores the digits as int16, [window][base][proof].
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars,
+static __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars,
                                                          const uint32_t* __restrict__ row_idx,
                                                          size_t Bp, uint32_t n, WinPlan plan,
                                                          int32_t kmul32, Fr koff,
@@ -286,9 +293,11 @@ __global__ __launch_bounds__(64) void msm_horner(HornerArgs<F> args, size_t Bp, 
 constexpr int COMB_W = 254;   // scalars are below 2^254
 
 // D[g][t] = P_t - (P_0 + ... + P_{t-1}): entry(m + 1) = entry(m) + D[number of trailing ones of m]
+// (signed tables: every step is twice that, so 2 D is stored); gsum[g] = sum of the group's bases
 template <class F>
 __global__ void comb_prep(const Affine<F>* __restrict__ bases, uint32_t n, uint32_t k,
-                          uint32_t n_groups, Affine<F>* __restrict__ dpts) {
+                          uint32_t n_groups, Affine<F>* __restrict__ dpts,
+                          Affine<F>* __restrict__ gsum, int twice) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   XYZZ<F> s = XYZZ<F>::inf();
@@ -298,13 +307,27 @@ __global__ void comb_prep(const Affine<F>* __restrict__ bases, uint32_t n, uint3
     XYZZ<F> d = s;
     d.y = neg(d.y);
     madd(d, P);
+    if (twice) d = dbl(d);
     dpts[i] = to_affine(d);
     madd(s, P);
   }
+  gsum[g] = to_affine(s);
+}
+// sum of the per-group sums (one thread: a few thousand mixed additions, once per key)
+template <class F>
+__global__ void comb_total(const Affine<F>* __restrict__ gsum, uint32_t n_groups,
+                           Affine<F>* __restrict__ out) {
+  XYZZ<F> s = XYZZ<F>::inf();
+  for (uint32_t g = 0; g < n_groups; g++) madd(s, gsum[g]);
+  *out = to_affine(s);
 }
 
-// one thread per (group, segment of seg_len consecutive subset masks)
-template <class F>
+// one thread per (group, segment of seg_len consecutive table indices).
+// Unsigned tables: entry m = sum of the bases whose bit is set in m (2^k entries, entry 0 unused).
+// SIGNED tables: entry e (k - 1 bits) = P_(k-1) + sum_{i < k-1} (e_i ? +P_i : -P_i): every k-bit
+// sign pattern or its complement has its top bit set, and sigma(~M) = -sigma(M), so 2^(k-1) entries
+// serve all 2^k patterns -- one more base per group in the same HBM.
+template <class F, bool SIGNED>
 __global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ bases,
                                                  const Affine<F>* __restrict__ dpts, uint32_t n,
                                                  uint32_t k, uint64_t r0, uint64_t n_rows,
@@ -314,14 +337,16 @@ __global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ b
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t r = r0 + t;
   if (t >= T || r >= n_rows) return;
-  const uint32_t per_group = 1u << k, segs = per_group / seg_len;
+  const uint32_t idx_bits = SIGNED ? k - 1 : k;
+  const uint32_t per_group = 1u << idx_bits, segs = per_group / seg_len;
   const uint32_t g = (uint32_t)(r / segs), m0 = (uint32_t)(r % segs) * seg_len;
   F* szz = scratch + t;
   F* szzz = scratch + (size_t)seg_len * T + t;
   F* spre = scratch + (size_t)2 * seg_len * T + t;
   Affine<F>* seg = table + (size_t)g * per_group + m0;
-  // subset sum of the first mask of the segment; `live` = bases that exist and are finite (the
-  // digit pass never sets the bit of any other base, so masks outside `live` are never gathered)
+  // entry of the first index of the segment; `live` = bases that exist and are finite (the
+  // unsigned digit pass never sets the bit of any other base, so masks outside `live` are never
+  // gathered)
   XYZZ<F> acc = XYZZ<F>::inf();
   uint32_t live = 0;
   for (uint32_t i = 0; i < k; i++) {
@@ -329,22 +354,29 @@ __global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ b
     if (bi >= n) continue;
     const Affine<F> P = bases[bi];
     if (!P.is_inf()) live |= 1u << i;
-    if ((m0 >> i) & 1u) madd(acc, P);
+    if (SIGNED) {
+      if (i == k - 1 || ((m0 >> i) & 1u))
+        madd(acc, P);
+      else
+        madd(acc, neg(P));
+    } else if ((m0 >> i) & 1u) {
+      madd(acc, P);
+    }
   }
   F pref = F::one();
   bool inf_seen = false;
   for (uint32_t d = 0; d < seg_len; d++) {
     const bool is_inf = acc.is_inf();
     const uint32_t m = m0 + d;
-    inf_seen = inf_seen || (is_inf && m != 0 && (m & ~live) == 0);
+    inf_seen = inf_seen || (is_inf && (SIGNED ? live != 0 : (m != 0 && (m & ~live) == 0)));
     seg[d].x = is_inf ? F::zero() : acc.x;
     seg[d].y = is_inf ? F::zero() : acc.y;
     szz[(size_t)d * T] = is_inf ? F::one() : acc.zz;
     szzz[(size_t)d * T] = is_inf ? F::one() : acc.zzz;
     spre[(size_t)d * T] = pref;
     pref = mul(pref, is_inf ? F::one() : acc.zzz);
-    const uint32_t tz = (uint32_t)__builtin_ctz(m0 + d + 1);   // trailing ones of the mask
-    if (tz < k) madd(acc, dpts[(size_t)g * k + tz]);
+    const uint32_t tz = (uint32_t)__builtin_ctz(m0 + d + 1);   // trailing ones of the index
+    if (tz < idx_bits) madd(acc, dpts[(size_t)g * k + tz]);
   }
   F inv = inverse(pref);
   for (uint32_t d = seg_len; d-- > 0;) {
@@ -359,7 +391,15 @@ __global__ __launch_bounds__(64) void comb_build(const Affine<F>* __restrict__ b
   if (inf_seen) atomicOr(any_inf, 1);
 }
 
-// Montgomery scalars -> plain integers, same planar layout (row i of the output = base i)
+// Montgomery scalars -> plain integers, same planar layout (row i of the output = base i).
+//
+// SIGNED (sign-pattern tables): every scalar is rewritten as a sum of 254 signed powers of two.
+//   t = s / 2 mod r;  e = 1 if t is even;  t' = t + e (odd, <= r);  C = (t' + 2^254 - 1) / 2 < 2^254
+//   => t' = sum_j (2 C_j - 1) 2^j, and  s P = 2 (t' P - e P).
+// Bit j of C is base i's sign in window j; the parity e rides in bit 255 and becomes the sign
+// pattern of one extra window (index 254) whose sum is subtracted once at the end together with
+// the sum of all bases:  sum_i s_i P_i = 2 H - W_254 - S,  H = sum_j 2^j W_j  (msm_horner_comb).
+template <bool SIGNED>
 __global__ __launch_bounds__(256) void comb_scalars_kernel(const Fr* __restrict__ scalars,
                                                            const uint32_t* __restrict__ row_idx,
                                                            size_t Bp, uint32_t n, int32_t kmul32,
@@ -368,23 +408,54 @@ __global__ __launch_bounds__(256) void comb_scalars_kernel(const Fr* __restrict_
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
     Fr s = Fr::zero();
-    if (!inf[i]) {   // the point at infinity contributes nothing: its bits never enter an index
+    if (!inf[i]) {   // the point at infinity contributes nothing: its bits never matter
       Fr29 kk = Fr29::zero();
       kk.v[0] = kmul32;
       const Fr raw = bi_ld(scalars, row_idx ? row_idx[i] : i, b, Bp);
       pack_canonical<Fr29Params>(s.v, mul(unpack29<Fr29Params>(raw.v), kk));
+      if (SIGNED) {
+        // t = (s + (s odd ? r : 0)) >> 1      (s + r < 2^255)
+        const uint32_t odd = s.v[0] & 1u;
+        uint64_t cy = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          cy += (uint64_t)s.v[l] + (odd ? FrParams::p(l) : 0u);
+          s.v[l] = (uint32_t)cy;
+          cy >>= 32;
+        }
+#pragma unroll
+        for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> 1) | (s.v[l + 1] << 31);
+        s.v[7] >>= 1;
+        const uint32_t e = (s.v[0] & 1u) ^ 1u;
+        // C = (t' - 1 + 2^254) >> 1 with t' = t + e = t | 1 (odd), so t' - 1 = t with bit 0 cleared;
+        // t' <= r < 2^254: the sum stays below 2^255
+        s.v[0] &= ~1u;
+        cy = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          cy += (uint64_t)s.v[l] + (l == 7 ? 0x40000000u : 0u);   // + 2^254
+          s.v[l] = (uint32_t)cy;
+          cy >>= 32;
+        }
+#pragma unroll
+        for (int l = 0; l < 7; l++) s.v[l] = (s.v[l] >> 1) | (s.v[l + 1] << 31);
+        s.v[7] = (s.v[7] >> 1) | (e << 31);
+      }
     }
     bi_st(out, i, b, Bp, s);
   }
 }
 
-// digits[j][g][b] = sum_i bit_j(s[gk+i][b]) << i
-template <int KMAX>
+// digits[j][g][b] = sum_i bit_j(s[gk+i][b]) << i.  SIGNED: k-bit sign pattern M -> (index, negate):
+// top bit set: entry M & (2^(k-1) - 1); clear: entry ~M & (2^(k-1) - 1), negated (bit 31 of the
+// digit).  Window 254 takes bit 255 of the rewritten scalars (the parity pattern).
+template <int KMAX, bool SIGNED>
 __global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__ sint, size_t Bp,
                                                           uint32_t n, uint32_t k, uint32_t n_groups,
                                                           uint32_t* __restrict__ digits) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint4* base = reinterpret_cast<const uint4*>(sint);
+  const uint32_t low = (1u << (k - 1)) - 1u;
   for (uint32_t g = blockIdx.y; g < n_groups; g += gridDim.y) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -397,14 +468,20 @@ __global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         for (int bit = 0; bit < 32; bit++) {
-          const int j = (h * 4 + c) * 32 + bit;
-          if (j >= COMB_W) break;
+          int j = (h * 4 + c) * 32 + bit;
+          if (SIGNED) {
+            if (j == 254) continue;     // C < 2^254
+            if (j == 255) j = 254;      // parity pattern
+          } else if (j >= COMB_W) {
+            break;
+          }
           uint32_t idx = 0;
 #pragma unroll
           for (int i = 0; i < KMAX; i++) {
             const uint32_t word = c == 0 ? wv[i].x : c == 1 ? wv[i].y : c == 2 ? wv[i].z : wv[i].w;
             idx |= ((word >> bit) & 1u) << i;
           }
+          if (SIGNED) idx = ((idx >> (k - 1)) & 1u) ? (idx & low) : ((~idx & low) | 0x80000000u);
           digits[((size_t)j * n_groups + g) * Bp + b] = idx;
         }
       }
@@ -412,8 +489,8 @@ __global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__
   }
 }
 
-// grid: x over proofs, y over the 254 bits, z over chunks of groups
-template <class F, bool CHECK_INF>
+// grid: x over proofs, y over the windows (254, or 255 for signed tables), z over chunks of groups
+template <class F, bool CHECK_INF, bool SIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void
 msm_accumulate_comb(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ digits,
                     size_t Bp, uint32_t n_groups, uint32_t per_chunk, uint32_t per_group,
@@ -427,7 +504,11 @@ msm_accumulate_comb(const Affine<F>* __restrict__ table, const uint32_t* __restr
   typename Acc29<F>::type acc = Acc29<F>::type::infinity();
   for (uint32_t g = g0; g < g1; g++) {
     const uint32_t m = dj[(size_t)g * Bp];
-    if (m) {
+    if (SIGNED) {   // a sign pattern is never "nothing to add"
+      const Affine<F> e = table[(size_t)g * per_group + (m & 0x7fffffffu)];
+      if (CHECK_INF && e.is_inf()) continue;
+      Acc29<F>::add(acc, e, (m >> 31) != 0);
+    } else if (m) {
       const Affine<F> e = table[(size_t)g * per_group + m];
       if (CHECK_INF && e.is_inf()) continue;
       Acc29<F>::add(acc, e, false);
@@ -444,6 +525,7 @@ template <class F>
 struct HornerArgsRW {
   XYZZ<F>* wsum[4];
   XYZZ<F>* out[4];
+  Affine<F> stotal[4];   // signed tables: sum of all bases of the MSM (standard Montgomery image)
 };
 template <class F>
 __global__ __launch_bounds__(64) void comb_fold8(HornerArgsRW<F> args, size_t Bp, int W) {
@@ -461,8 +543,10 @@ __global__ __launch_bounds__(64) void comb_fold8(HornerArgsRW<F> args, size_t Bp
   }
   wsum[(size_t)j0 * Bp + b] = acc;
 }
+// W = number of power-of-two windows (254).  signed_tail: out = 2 H - wsum[W] - stotal.
 template <class F>
-__global__ __launch_bounds__(64) void msm_horner_comb(HornerArgsRW<F> args, size_t Bp, int W) {
+__global__ __launch_bounds__(64) void msm_horner_comb(HornerArgsRW<F> args, size_t Bp, int W,
+                                                      int signed_tail) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= Bp) return;
   const XYZZ<F>* __restrict__ wsum = args.wsum[blockIdx.y];
@@ -474,16 +558,24 @@ __global__ __launch_bounds__(64) void msm_horner_comb(HornerArgsRW<F> args, size
     const XYZZ<F> p = wsum[(size_t)(8 * q) * Bp + b];
     padd(acc, p);
   }
+  if (signed_tail) {
+    acc = dbl(acc);
+    XYZZ<F> corr = wsum[(size_t)W * Bp + b];
+    corr.y = neg(corr.y);
+    padd(acc, corr);
+    madd(acc, neg(args.stotal[blockIdx.y]));
+  }
   args.out[blockIdx.y][b] = acc;
 }
 template <class F>
 static void launch_comb_horner(hipStream_t stream, const HornerArgsRW<F>& ha, int count, size_t Bp,
-                               int W) {
+                               const WinPlan& plan) {
+  const int W = COMB_W;   // plan.W = 254, or 255 with the correction window of signed tables
   hipLaunchKernelGGL((comb_fold8<F>),
                      dim3((unsigned)(Bp / 64), (unsigned)count, (unsigned)((W + 7) / 8)), dim3(64), 0,
                      stream, ha, Bp, W);
   hipLaunchKernelGGL((msm_horner_comb<F>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
-                     stream, ha, Bp, W);
+                     stream, ha, Bp, W, (int)plan.comb_signed);
 }
 
 // sums groups of `group` consecutive chunk partials: out[g][b] = sum_{k < group} in[g*group + k][b]
@@ -516,6 +608,7 @@ __global__ __launch_bounds__(64) void xyzz_to_affine_kernel(const XYZZ<F>* __res
   out[i] = to_affine(in[i]);
 }
 
+#if ZK_MSM_PART == 1
 // ---- host side -------------------------------------------------------------------------------------
 // ---- window plans ----------------------------------------------------------------------------------
 WinPlan plan_with_windows(int W) {
@@ -558,32 +651,44 @@ WinPlan plan_shared(int c) {   // ceil(255 / c) windows over ONE table of 2^(c-1
   p.per_base = 1u << (c - 1);
   return p;
 }
-WinPlan plan_comb(int k) {
+WinPlan plan_comb(int k, bool signed_tables) {
   WinPlan p;
   if (k < 2) k = 2;
-  if (k > 20) k = 20;
+  if (k > 21) k = 21;
+  if (!signed_tables && k > 20) k = 20;
   p.comb = (uint8_t)k;
-  p.W = COMB_W;
+  p.comb_signed = signed_tables ? 1 : 0;
+  p.W = COMB_W + (signed_tables ? 1 : 0);   // + the parity-correction window
   p.per_base = 0;
   return p;
 }
-// Group sizes of the comb tables of a key: the (k1, k2) minimising n1 / k1 + 3 * n2 / k2 among those
-// whose tables (2^k entries per group) fit `usable_bytes`.
-void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2) {
+// Comb plan of a key: group sizes (k1, k2) and table kinds minimising the estimated accumulate
+// time among the plans whose tables fit `usable_bytes`.  Sign-pattern tables hold 2^(k-1) entries
+// per group and need 255 windows, subset-sum tables 2^k entries and 254 windows.  Relative cost of
+// one mixed addition, measured on MI355X (Arbo-160 key, ns per (group, window) at 1024 proofs):
+// G1 subset-sum 61.1, G1 sign-pattern 62.8 (the per-lane negation), G2 subset-sum 171.6, G2
+// sign-pattern 198.8 (the 256-register G2 kernel spills more with the extra live sign).
+void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2, bool* sg1,
+                          bool* sg2) {
   double best = 1e300;
   *k1 = *k2 = 8;
-  for (int a = 8; a <= 20; a++)
-    for (int b = 8; b <= 20; b++) {
-      const double g1 = (double)((n1 + a - 1) / a), g2 = (double)((n2 + b - 1) / b);
-      const double bytes = g1 * (double)(1u << a) * 64.0 + g2 * (double)(1u << b) * 128.0;
-      if (bytes > usable_bytes) continue;
-      const double cost = g1 + 3.0 * g2;
-      if (cost < best) {
-        best = cost;
-        *k1 = a;
-        *k2 = b;
-      }
-    }
+  *sg1 = *sg2 = true;
+  for (int s1 = 0; s1 < 2; s1++)
+    for (int s2 = 0; s2 < 2; s2++)
+      for (int a = 8; a <= (s1 ? 21 : 20); a++)
+        for (int b = 8; b <= (s2 ? 21 : 20); b++) {
+          const double g1 = (double)((n1 + a - 1) / a), g2 = (double)((n2 + b - 1) / b);
+          const double bytes = g1 * (double)(1u << (a - s1)) * 64.0 + g2 * (double)(1u << (b - s2)) * 128.0;
+          if (bytes > usable_bytes) continue;
+          const double cost = g1 * (s1 ? 255 * 62.8 : 254 * 61.1) + g2 * (s2 ? 255 * 198.8 : 254 * 171.6);
+          if (cost < best) {
+            best = cost;
+            *k1 = a;
+            *k2 = b;
+            *sg1 = s1 != 0;
+            *sg2 = s2 != 0;
+          }
+        }
 }
 // Widths of the shared tables of a key: the (c1, c2) that minimises n1 * W(c1) + 3 * n2 * W(c2)
 // (a G2 mixed addition costs about three G1 ones) among those whose tables fit `usable_bytes`.
@@ -611,6 +716,8 @@ WinPlan plan_windows_for_budget(size_t n_total, int group, double budget_bytes) 
   return plan_with_windows(64);
 }
 
+#endif  // ZK_MSM_PART == 1
+
 // inf[i] = 1 when base i is the point at infinity: its table rows are zeros and must never reach a
 // mixed addition (the digit pass / the accumulate loop skip the base)
 template <class F>
@@ -621,11 +728,12 @@ __global__ void msm_inf_flags(const Affine<F>* __restrict__ bases, uint32_t n,
 }
 
 template <class F>
-static int build_comb(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
-                      Affine<F>* table, int* any_inf_host) {
+int build_comb(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
+                      Affine<F>* table, int* any_inf_host, Affine<F>* stotal_host) {
   const uint32_t k = plan.comb;
+  const bool sg = plan.comb_signed != 0;
   const size_t n_groups = (n + k - 1) / k;
-  const uint32_t per_group = 1u << k;
+  const uint32_t per_group = 1u << (sg ? k - 1 : k);
   const uint32_t seg_len = per_group < 512u ? per_group : 512u;
   const uint64_t n_rows = (uint64_t)n_groups * (per_group / seg_len);
   const size_t per_thread = (size_t)3 * seg_len * sizeof(F);
@@ -635,26 +743,39 @@ static int build_comb(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const
   if (T > 262144) T = 262144;
   void* scratch;
   const size_t dp_bytes = round_up(n_groups * k * sizeof(Affine<F>), 256);
-  int rc = ensure_scratch(ctx, 7, dp_bytes + 256 + per_thread * T, &scratch);
+  const size_t gs_bytes = round_up((n_groups + 1) * sizeof(Affine<F>), 256);
+  int rc = ensure_scratch(ctx, 7, dp_bytes + gs_bytes + 256 + per_thread * T, &scratch);
   if (rc) return rc;
   Affine<F>* dpts = (Affine<F>*)scratch;
-  int* any_inf = (int*)((char*)scratch + dp_bytes);
-  F* inv_scratch = (F*)((char*)scratch + dp_bytes + 256);
+  Affine<F>* gsum = (Affine<F>*)((char*)scratch + dp_bytes);
+  int* any_inf = (int*)((char*)scratch + dp_bytes + gs_bytes);
+  F* inv_scratch = (F*)((char*)scratch + dp_bytes + gs_bytes + 256);
   ZK_HIP(hipMemsetAsync(any_inf, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL((comb_prep<F>), dim3((unsigned)((n_groups + 63) / 64)), dim3(64), 0,
-                     ctx->stream, bases_dev, (uint32_t)n, k, (uint32_t)n_groups, dpts);
-  for (uint64_t r0 = 0; r0 < n_rows; r0 += T)
-    hipLaunchKernelGGL((comb_build<F>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
-                       bases_dev, (const Affine<F>*)dpts, (uint32_t)n, k, r0, n_rows, table,
-                       inv_scratch, (uint32_t)T, seg_len, any_inf);
+                     ctx->stream, bases_dev, (uint32_t)n, k, (uint32_t)n_groups, dpts, gsum,
+                     sg ? 1 : 0);
+  hipLaunchKernelGGL((comb_total<F>), dim3(1), dim3(1), 0, ctx->stream, (const Affine<F>*)gsum,
+                     (uint32_t)n_groups, gsum + n_groups);
+  for (uint64_t r0 = 0; r0 < n_rows; r0 += T) {
+    if (sg)
+      hipLaunchKernelGGL((comb_build<F, true>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
+                         bases_dev, (const Affine<F>*)dpts, (uint32_t)n, k, r0, n_rows, table,
+                         inv_scratch, (uint32_t)T, seg_len, any_inf);
+    else
+      hipLaunchKernelGGL((comb_build<F, false>), dim3((unsigned)(T / 64)), dim3(64), 0, ctx->stream,
+                         bases_dev, (const Affine<F>*)dpts, (uint32_t)n, k, r0, n_rows, table,
+                         inv_scratch, (uint32_t)T, seg_len, any_inf);
+  }
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipMemcpyAsync(any_inf_host, any_inf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(hipMemcpyAsync(stotal_host, gsum + n_groups, sizeof(Affine<F>), hipMemcpyDeviceToHost,
+                        ctx->stream));
   ZK_HIP(hipStreamSynchronize(ctx->stream));
   return ZKMI_OK;
 }
 
 template <class F>
-static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
+int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const WinPlan& plan,
                       Affine<F>* table) {
   const uint32_t Dmax = plan.shared ? plan.per_base : 1u << (plan.bits[0] - 1);
   const uint32_t seg_len = Dmax < 512u ? Dmax : 512u;
@@ -677,6 +798,11 @@ static int build_impl(zkmi_ctx* ctx, const Affine<F>* bases_dev, size_t n, const
   return ZKMI_OK;
 }
 
+#if ZK_MSM_PART == 1
+extern template int build_comb<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPlan&,
+                                    Affine<Fq2>*, int*, Affine<Fq2>*);
+extern template int build_impl<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPlan&,
+                                    Affine<Fq2>*);
 int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, const WinPlan& plan,
                     zkmi_msm_bases** out) {
   if (group != 1 && group != 2) {
@@ -689,7 +815,7 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
   b->plan = plan;
   const size_t entry = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
   b->n_groups = plan.comb ? (n + plan.comb - 1) / plan.comb : 0;
-  b->table_bytes = plan.comb ? b->n_groups * ((size_t)1 << plan.comb) * entry
+  b->table_bytes = plan.comb ? b->n_groups * ((size_t)1 << (plan.comb - plan.comb_signed)) * entry
                              : n * (size_t)plan.per_base * entry;
   if (n == 0) {
     *out = b;
@@ -718,9 +844,9 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
   int rc;
   if (plan.comb)
     rc = group == 1 ? build_comb<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table,
-                                     &b->entries_may_be_inf)
+                                     &b->entries_may_be_inf, &b->stotal1)
                     : build_comb<Fq2>(ctx, (const G2Affine*)bases_dev, n, plan,
-                                      (G2Affine*)b->table, &b->entries_may_be_inf);
+                                      (G2Affine*)b->table, &b->entries_may_be_inf, &b->stotal2);
   else
     rc = group == 1
              ? build_impl<Fq>(ctx, (const G1Affine*)bases_dev, n, plan, (G1Affine*)b->table)
@@ -735,8 +861,14 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
   return ZKMI_OK;
 }
 
+#endif  // ZK_MSM_PART == 1
+
+template <class F> static Affine<F> stotal_of(const zkmi_msm_bases* b);
+template <> Affine<Fq> stotal_of<Fq>(const zkmi_msm_bases* b) { return b->stotal1; }
+template <> Affine<Fq2> stotal_of<Fq2>(const zkmi_msm_bases* b) { return b->stotal2; }
+
 template <class F>
-static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
+int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
                     const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f,
                     XYZZ<F>* wsum_out, hipStream_t finish_stream) {
   Fr kmul = Fr::zero();
@@ -749,8 +881,9 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   const size_t n = bases->n;
   if (bases->plan.comb) {
     const uint32_t k = bases->plan.comb;
+    const bool sg = bases->plan.comb_signed != 0;
     const size_t G = bases->n_groups;
-    const int W = COMB_W;
+    const int W = bases->plan.W;   // 254, + the correction window of signed tables
     // measured at 4 / 8 / 12 / 16 / 24: 277 / 275 / 273.5 / 272 / 273.6 ms per Arbo-160 batch
     const size_t comb_factor = bases->chunk_factor ? bases->chunk_factor : 16;
     size_t chunks = comb_factor * 262144 / Bp / (size_t)W;
@@ -778,14 +911,20 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
     XYZZ<F>* wsum = wsum_out ? wsum_out : mid + (size_t)ngroups * W * Bp;
     const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
-    hipLaunchKernelGGL(comb_scalars_kernel,
-                       dim3((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384)), dim3(bx), 0,
-                       ctx->stream, scalars, row_idx, Bp, (uint32_t)n,
-                       (int32_t)(scalars_f ? 1 : 32), (const uint8_t*)bases->inf, (Fr*)sint);
-    hipLaunchKernelGGL((comb_digits_kernel<20>),
-                       dim3((unsigned)(Bp / bx), (unsigned)(G < 8192 ? G : 8192)), dim3(bx), 0,
-                       ctx->stream, (const Fr*)sint, Bp, (uint32_t)n, k, (uint32_t)G,
-                       (uint32_t*)digits);
+    const dim3 sgrid((unsigned)(Bp / bx), (unsigned)(n < 16384 ? n : 16384));
+    const dim3 dgrid((unsigned)(Bp / bx), (unsigned)(G < 8192 ? G : 8192));
+    const int32_t km = (int32_t)(scalars_f ? 1 : 32);
+    if (sg) {
+      hipLaunchKernelGGL((comb_scalars_kernel<true>), sgrid, dim3(bx), 0, ctx->stream, scalars,
+                         row_idx, Bp, (uint32_t)n, km, (const uint8_t*)bases->inf, (Fr*)sint);
+      hipLaunchKernelGGL((comb_digits_kernel<21, true>), dgrid, dim3(bx), 0, ctx->stream,
+                         (const Fr*)sint, Bp, (uint32_t)n, k, (uint32_t)G, (uint32_t*)digits);
+    } else {
+      hipLaunchKernelGGL((comb_scalars_kernel<false>), sgrid, dim3(bx), 0, ctx->stream, scalars,
+                         row_idx, Bp, (uint32_t)n, km, (const uint8_t*)bases->inf, (Fr*)sint);
+      hipLaunchKernelGGL((comb_digits_kernel<20, false>), dgrid, dim3(bx), 0, ctx->stream,
+                         (const Fr*)sint, Bp, (uint32_t)n, k, (uint32_t)G, (uint32_t*)digits);
+    }
     zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
     const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
     if (ev >= 0) {
@@ -793,14 +932,17 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
       hipEventRecord(es->msm_ev[ev][0], ctx->stream);
     }
     const dim3 grid((unsigned)(Bp / bx), (unsigned)W, (unsigned)chunks);
-    if (bases->entries_may_be_inf)
-      hipLaunchKernelGGL((msm_accumulate_comb<F, true>), grid, dim3(bx), 0, ctx->stream,
-                         (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G,
-                         per_chunk, 1u << k, (XYZZ<F>*)partial);
-    else
-      hipLaunchKernelGGL((msm_accumulate_comb<F, false>), grid, dim3(bx), 0, ctx->stream,
-                         (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G,
-                         per_chunk, 1u << k, (XYZZ<F>*)partial);
+    const uint32_t per_group = 1u << (sg ? k - 1 : k);
+#define ZK_LAUNCH_COMB(CI, SG)                                                                   \
+    hipLaunchKernelGGL((msm_accumulate_comb<F, CI, SG>), grid, dim3(bx), 0, ctx->stream,        \
+                       (const Affine<F>*)bases->table, (const uint32_t*)digits, Bp, (uint32_t)G, \
+                       per_chunk, per_group, (XYZZ<F>*)partial)
+    if (bases->entries_may_be_inf) {
+      if (sg) ZK_LAUNCH_COMB(true, true); else ZK_LAUNCH_COMB(true, false);
+    } else {
+      if (sg) ZK_LAUNCH_COMB(false, true); else ZK_LAUNCH_COMB(false, false);
+    }
+#undef ZK_LAUNCH_COMB
     if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
     hipStream_t rq = ctx->stream;
     if (defer) {
@@ -828,7 +970,8 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
       HornerArgsRW<F> ha{};
       ha.wsum[0] = wsum;
       ha.out[0] = out;
-      launch_comb_horner<F>(ctx->stream, ha, 1, Bp, W);
+      ha.stotal[0] = stotal_of<F>(bases);
+      launch_comb_horner<F>(ctx->stream, ha, 1, Bp, bases->plan);
     }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
@@ -913,12 +1056,7 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   // run for the whole kernel, so a few occupied wave slots (the overlapped solve of the next
   // batch) or uneven clocks cost a full extra round; measured per 1024-proof batch, G1 launches:
   // x1 325 ms, x2 315, x4 299, x8 292 (best end to end), x16 289 + dearer reduction.
-  // ZKMI_MSM_CHUNKS overrides.
-  static const size_t chunk_factor = [] {
-    const char* e = getenv("ZKMI_MSM_CHUNKS");
-    const long v = e ? atol(e) : 8;
-    return (size_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
-  }();
+  const size_t chunk_factor = bases->chunk_factor ? bases->chunk_factor : 8;
   size_t chunks = chunk_factor * (size_t)262144 / Bp;
   if (chunks < 1) chunks = 1;
   if (chunks > n) chunks = n;
@@ -932,11 +1070,7 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[0], 0));
     ctx->part_ev_valid[0] = false;
   }
-  static const unsigned bx_cfg = [] {
-    const char* e = getenv("ZKMI_MSM_BLOCK");
-    const long v = e ? atol(e) : 256;
-    return (unsigned)(v == 64 || v == 128 ? v : 256);
-  }();
+  const unsigned bx_cfg = 256;
   const unsigned bx = (Bp % bx_cfg == 0) ? bx_cfg : 64;
   zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
   const int ev = (es && n > 1 && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
@@ -974,6 +1108,16 @@ static int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalar
   return ZKMI_OK;
 }
 
+#if ZK_MSM_PART == 2
+template int build_comb<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPlan&, Affine<Fq2>*,
+                             int*, Affine<Fq2>*);
+template int build_impl<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPlan&, Affine<Fq2>*);
+template int run_impl<Fq2>(zkmi_ctx*, const zkmi_msm_bases*, const Fr*, const uint32_t*, size_t,
+                           XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t);
+#else
+extern template int run_impl<Fq2>(zkmi_ctx*, const zkmi_msm_bases*, const Fr*, const uint32_t*,
+                                  size_t, XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t);
+
 __global__ void fill_inf_g1(G1XYZZ* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = G1XYZZ::inf();
@@ -984,41 +1128,48 @@ __global__ void fill_inf_g2(G2XYZZ* out, size_t n) {
 }
 
 // Horner step of up to four deferred MSMs of one group (same plan) in one launch on `stream`
-int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& plan, int count,
-                   void* const* wsums, void* const* outs, size_t Bp) {
+int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int count,
+                   const zkmi_msm_bases* const* bases, void* const* wsums, void* const* outs,
+                   size_t Bp) {
   if (count < 1 || count > 4) return ZKMI_ERR_ARG;
+  const int group = bases[0]->group;
+  const WinPlan& plan = bases[0]->plan;
   if (group == 1) {
-    HornerArgs<Fq> ha{};
-    for (int i = 0; i < count; i++) {
-      ha.wsum[i] = (const G1XYZZ*)wsums[i];
-      ha.out[i] = (G1XYZZ*)outs[i];
-    }
     if (plan.comb) {
       HornerArgsRW<Fq> hw{};
       for (int i = 0; i < count; i++) {
         hw.wsum[i] = (G1XYZZ*)wsums[i];
         hw.out[i] = (G1XYZZ*)outs[i];
+        hw.stotal[i] = bases[i]->stotal1;
       }
-      launch_comb_horner<Fq>(stream, hw, count, Bp, plan.W);
-    } else
+      launch_comb_horner<Fq>(stream, hw, count, Bp, plan);
+    } else {
+      HornerArgs<Fq> ha{};
+      for (int i = 0; i < count; i++) {
+        ha.wsum[i] = (const G1XYZZ*)wsums[i];
+        ha.out[i] = (G1XYZZ*)outs[i];
+      }
       hipLaunchKernelGGL((msm_horner<Fq>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64), 0,
                          stream, ha, Bp, plan);
-  } else {
-    HornerArgs<Fq2> ha{};
-    for (int i = 0; i < count; i++) {
-      ha.wsum[i] = (const G2XYZZ*)wsums[i];
-      ha.out[i] = (G2XYZZ*)outs[i];
     }
+  } else {
     if (plan.comb) {
       HornerArgsRW<Fq2> hw{};
       for (int i = 0; i < count; i++) {
         hw.wsum[i] = (G2XYZZ*)wsums[i];
         hw.out[i] = (G2XYZZ*)outs[i];
+        hw.stotal[i] = bases[i]->stotal2;
       }
-      launch_comb_horner<Fq2>(stream, hw, count, Bp, plan.W);
-    } else
+      launch_comb_horner<Fq2>(stream, hw, count, Bp, plan);
+    } else {
+      HornerArgs<Fq2> ha{};
+      for (int i = 0; i < count; i++) {
+        ha.wsum[i] = (const G2XYZZ*)wsums[i];
+        ha.out[i] = (G2XYZZ*)outs[i];
+      }
       hipLaunchKernelGGL((msm_horner<Fq2>), dim3((unsigned)(Bp / 64), (unsigned)count), dim3(64),
                          0, stream, ha, Bp, plan);
+    }
   }
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
@@ -1067,5 +1218,7 @@ int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
 }
+
+#endif  // ZK_MSM_PART
 
 }  // namespace zk

@@ -1,0 +1,616 @@
+// PLONK prover rounds for a batch of independent witnesses (BASELINE config 5 names the PLONK
+// backend).  Stands in for plonk.Prove in gnark backend/plonk/bn254/prove.go [UPSTREAM-RECALL,
+// SURVEY.md §3.2, §8 a-2 / f-4]: KZG commitments (G1 MSMs over the SRS: the same fixed-base comb
+// tables as the Groth16 key), wire polynomials blinded with multiples of Z_H, grand-product
+// permutation argument, quotient on the coset 5<w_4n> split in three, linearisation and two
+// openings.  The Fiat-Shamir hashing stays on the host between rounds, as in gnark (the five
+// zkmi_plonk_round* calls); everything else runs here.  Protocol: DESIGN.md §PLONK; the reference
+// holds no PLONK vector: parity unpinned, pinned instead to oracle/plonk_ref.py and to the pairing
+// check of the openings.
+//
+// Layout: as everywhere, batch-inner.  A polynomial of a batch is a matrix [coefficient][proof]
+// with the proof index fastest: lane = proof, so the sequential recurrences of the protocol
+// (grand product, Horner evaluation, division by X - zeta) are plain per-lane loops that run for
+// the whole batch at once, and every key-side quantity (selectors, sigma, coset points) is
+// wave-uniform.  Field elements are in gnark's image (x * 2^256, ff.h) throughout.
+#include <algorithm>
+
+#include "zkmi_internal.h"
+
+using namespace zk;
+
+struct zkmi_plonk_pk {
+  uint32_t log_n = 0, n_public = 0, max_batch = 0;
+  Fr *coef = nullptr, *coset = nullptr, *sigma = nullptr, *omega = nullptr, *coset_x = nullptr,
+     *l1 = nullptr, *zh_inv = nullptr;
+  zkmi_msm_bases* srs = nullptr;
+  uint32_t* chunk_idx = nullptr;   // 3 x (n + 6): scalar rows of t_lo / t_mid / t_hi in the 4n buffer
+  // state of the batch in flight
+  size_t batch = 0, Bp = 0;
+  int round = 0;
+  DevBuf cf[4];      // coefficient forms of a, b, c, z: (n + 8) rows
+  DevBuf big[6];     // 4n-row work buffers
+  DevBuf small[4];   // challenges / per-proof scalars, MSM outputs
+};
+
+namespace zk {
+
+#define LANE const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x
+
+// cf[j] -= b_j, cf[n + j] += b_j: adds (b_(nb-1) X^(nb-1) + ... + b_0)(X^n - 1); the blinding rows
+// of `blind` are ordered highest power first (b1 X + b2 -> rows r0, r0 + 1)
+__global__ void plonk_blind(Fr* cf, size_t n, const Fr* blind, int r0, int nb, size_t Bp) {
+  LANE;
+  for (int j = 0; j < nb; j++) {
+    const Fr bj = bi_ld(blind, r0 + nb - 1 - j, lane, Bp);
+    bi_st(cf, j, lane, Bp, sub(bi_ld(cf, j, lane, Bp), bj));
+    bi_st(cf, n + j, lane, Bp, add(bi_ld(cf, n + j, lane, Bp), bj));
+  }
+}
+
+__global__ void plonk_zero_rows(Fr* p, size_t r0, size_t r1, size_t Bp) {
+  LANE;
+  for (size_t r = r0 + blockIdx.y; r < r1; r += gridDim.y) bi_st(p, r, lane, Bp, Fr::zero());
+}
+
+// PI Lagrange values: row j = -x_j for the public inputs (rows 0 .. n_pub-1 of `inputs`), else 0
+__global__ void plonk_pi(const Fr* inputs, Fr* pi, size_t n_pub, size_t n, size_t Bp) {
+  LANE;
+  for (size_t r = blockIdx.y; r < n; r += gridDim.y)
+    bi_st(pi, r, lane, Bp, r < n_pub ? neg(bi_ld(inputs, r, lane, Bp)) : Fr::zero());
+}
+
+// F[i] = prod_c (w_c,i + beta k_c w^i + gamma), G[i] = prod_c (w_c,i + beta sigma_c,i + gamma)
+__global__ __launch_bounds__(64) void plonk_fg(const Fr* a, const Fr* b, const Fr* c,
+                                               const Fr* sigma, const Fr* omega, const Fr* ch,
+                                               Fr* F, Fr* G, size_t n, size_t Bp, Fr k1, Fr k2) {
+  LANE;
+  const Fr beta = bi_ld(ch, 0, lane, Bp), gamma = bi_ld(ch, 1, lane, Bp);
+  for (size_t i = blockIdx.y; i < n; i += gridDim.y) {
+    const Fr bx = mul(beta, omega[i]);
+    const Fr wa = add(bi_ld(a, i, lane, Bp), gamma), wb = add(bi_ld(b, i, lane, Bp), gamma),
+             wc = add(bi_ld(c, i, lane, Bp), gamma);
+    const Fr f = mul(mul(add(wa, bx), add(wb, mul(bx, k1))), add(wc, mul(bx, k2)));
+    const Fr g = mul(mul(add(wa, mul(beta, sigma[i])), add(wb, mul(beta, sigma[n + i]))),
+                     add(wc, mul(beta, sigma[2 * n + i])));
+    bi_st(F, i, lane, Bp, f);
+    bi_st(G, i, lane, Bp, g);
+  }
+}
+
+// per (lane, chunk): ratio[i] = F[i] / G[i] with one inversion per chunk (Montgomery's trick; P is
+// prefix scratch), then the chunk's product into cp[chunk]
+__global__ __launch_bounds__(64) void plonk_ratio(Fr* F, const Fr* G, Fr* P, Fr* cp, size_t n,
+                                                  size_t chunk, size_t Bp) {
+  LANE;
+  const size_t i0 = (size_t)blockIdx.y * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+  Fr acc = Fr::one();
+  for (size_t i = i0; i < i1; i++) {
+    bi_st(P, i, lane, Bp, acc);
+    acc = mul(acc, bi_ld(G, i, lane, Bp));
+  }
+  Fr inv = inverse(acc);
+  for (size_t i = i1; i-- > i0;) {
+    const Fr gi = mul(inv, bi_ld(P, i, lane, Bp));
+    inv = mul(inv, bi_ld(G, i, lane, Bp));
+    bi_st(F, i, lane, Bp, mul(bi_ld(F, i, lane, Bp), gi));
+  }
+  acc = Fr::one();
+  for (size_t i = i0; i < i1; i++) acc = mul(acc, bi_ld(F, i, lane, Bp));
+  bi_st(cp, blockIdx.y, lane, Bp, acc);
+}
+// exclusive prefix product of the chunk products, per lane
+__global__ void plonk_chunk_scan(Fr* cp, size_t n_chunks, size_t Bp) {
+  LANE;
+  Fr acc = Fr::one();
+  for (size_t k = 0; k < n_chunks; k++) {
+    const Fr v = bi_ld(cp, k, lane, Bp);
+    bi_st(cp, k, lane, Bp, acc);
+    acc = mul(acc, v);
+  }
+}
+// z[i0] = carry-in, z[i + 1] = z[i] * ratio[i]
+__global__ __launch_bounds__(64) void plonk_z_fill(const Fr* ratio, const Fr* cp, Fr* z, size_t n,
+                                                   size_t chunk, size_t Bp) {
+  LANE;
+  const size_t i0 = (size_t)blockIdx.y * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+  Fr acc = bi_ld(cp, blockIdx.y, lane, Bp);
+  for (size_t i = i0; i < i1; i++) {
+    bi_st(z, i, lane, Bp, acc);
+    acc = mul(acc, bi_ld(ratio, i, lane, Bp));
+  }
+}
+
+// quotient on the coset: T[j] = (gate + alpha (p1 - p2) + alpha^2 (z - 1) L1) / Z_H
+// key-side arrays (`ks`: qL, qR, qO, qM, qC, S1, S2, S3 on the coset, 4n each) are wave-uniform
+__global__ __launch_bounds__(64) void plonk_quotient(const Fr* ea, const Fr* eb, const Fr* ec,
+                                                     const Fr* ez, const Fr* epi, const Fr* ks,
+                                                     const Fr* xs, const Fr* l1, const Fr* zh_inv,
+                                                     const Fr* ch, Fr* T, size_t m, size_t Bp,
+                                                     Fr k1, Fr k2) {
+  LANE;
+  const Fr beta = bi_ld(ch, 0, lane, Bp), gamma = bi_ld(ch, 1, lane, Bp),
+           alpha = bi_ld(ch, 2, lane, Bp);
+  for (size_t j = blockIdx.y; j < m; j += gridDim.y) {
+    const Fr a = bi_ld(ea, j, lane, Bp), b = bi_ld(eb, j, lane, Bp), c = bi_ld(ec, j, lane, Bp),
+             z = bi_ld(ez, j, lane, Bp), zw = bi_ld(ez, (j + 4) & (m - 1), lane, Bp);
+    Fr gate = add(add(mul(ks[j], a), mul(ks[m + j], b)), mul(ks[2 * m + j], c));
+    gate = add(add(gate, mul(ks[3 * m + j], mul(a, b))), add(ks[4 * m + j], bi_ld(epi, j, lane, Bp)));
+    const Fr bx = mul(beta, xs[j]);
+    const Fr ag = add(a, gamma), bg = add(b, gamma), cg = add(c, gamma);
+    const Fr p1 = mul(mul(mul(add(ag, bx), add(bg, mul(bx, k1))), add(cg, mul(bx, k2))), z);
+    const Fr p2 = mul(mul(mul(add(ag, mul(beta, ks[5 * m + j])), add(bg, mul(beta, ks[6 * m + j]))),
+                          add(cg, mul(beta, ks[7 * m + j]))),
+                      zw);
+    const Fr t3 = mul(mul(mul(alpha, alpha), sub(z, Fr::one())), l1[j]);
+    const Fr num = add(add(gate, mul(alpha, sub(p1, p2))), t3);
+    bi_st(T, j, lane, Bp, mul(num, zh_inv[j & 3]));
+  }
+}
+
+// Horner evaluation of `count` polynomials at per-lane points: blockIdx.y selects the polynomial.
+// shared != 0: the polynomial is key-side (one coefficient array for all proofs)
+struct EvalArgs {
+  const Fr* poly[6];
+  uint32_t len[6];
+  uint8_t shared[6];
+  uint8_t point_row[6];   // row of `pts` holding the evaluation point
+};
+__global__ __launch_bounds__(64) void plonk_eval(EvalArgs args, const Fr* pts, Fr* out, size_t Bp) {
+  LANE;
+  const int k = blockIdx.y;
+  const Fr x = bi_ld(pts, args.point_row[k], lane, Bp);
+  const Fr* p = args.poly[k];
+  Fr acc = Fr::zero();
+  if (args.shared[k]) {
+    for (size_t i = args.len[k]; i-- > 0;) acc = add(mul(acc, x), p[i]);
+  } else {
+    for (size_t i = args.len[k]; i-- > 0;) acc = add(mul(acc, x), bi_ld(p, i, lane, Bp));
+  }
+  bi_st(out, k, lane, Bp, acc);
+}
+
+// numerators of the two openings.  sc rows: 0 qm, 1 ql, 2 qr, 3 qo, 4 s3, 5 z, 6 tlo, 7 tmid, 8 thi,
+// 9 c0 (constant term: r0 - sum_i v^i e_i), 10 v, 11 zeta, 12 zeta*w, 13 z(zeta w)
+__global__ __launch_bounds__(64) void plonk_lin(const Fr* ca, const Fr* cb, const Fr* cc,
+                                                const Fr* cz, const Fr* t, const Fr* kc,
+                                                const Fr* sc, Fr* N, Fr* NZ, size_t n, size_t Bp) {
+  LANE;
+  const Fr v = bi_ld(sc, 10, lane, Bp);
+  const Fr v2 = mul(v, v), v3 = mul(v2, v), v4 = mul(v3, v), v5 = mul(v4, v);
+  const Fr sqm = bi_ld(sc, 0, lane, Bp), sql = bi_ld(sc, 1, lane, Bp), sqr_ = bi_ld(sc, 2, lane, Bp),
+           sqo = bi_ld(sc, 3, lane, Bp), ss3 = bi_ld(sc, 4, lane, Bp), sz = bi_ld(sc, 5, lane, Bp),
+           stl = bi_ld(sc, 6, lane, Bp), stm = bi_ld(sc, 7, lane, Bp), sth = bi_ld(sc, 8, lane, Bp);
+  const size_t L = n + 3;
+  for (size_t i = blockIdx.y; i < L; i += gridDim.y) {
+    Fr r = Fr::zero();
+    if (i < n) {   // key polynomials: qL qR qO qM qC S1 S2 S3 coefficient forms, n each
+      r = add(add(mul(sql, kc[i]), mul(sqr_, kc[n + i])), add(mul(sqo, kc[2 * n + i]), mul(sqm, kc[3 * n + i])));
+      r = add(r, add(kc[4 * n + i], mul(ss3, kc[7 * n + i])));
+      r = add(r, add(mul(v4, kc[5 * n + i]), mul(v5, kc[6 * n + i])));
+    }
+    const Fr zi = bi_ld(cz, i, lane, Bp);
+    r = add(r, mul(sz, zi));
+    if (i < n + 2) {
+      r = add(r, add(mul(stl, bi_ld(t, i, lane, Bp)),
+                     add(mul(stm, bi_ld(t, n + 2 + i, lane, Bp)), mul(sth, bi_ld(t, 2 * n + 4 + i, lane, Bp)))));
+      r = add(r, add(mul(v, bi_ld(ca, i, lane, Bp)),
+                     add(mul(v2, bi_ld(cb, i, lane, Bp)), mul(v3, bi_ld(cc, i, lane, Bp)))));
+    }
+    if (i == 0) r = add(r, bi_ld(sc, 9, lane, Bp));
+    bi_st(N, i, lane, Bp, r);
+    bi_st(NZ, i, lane, Bp, i == 0 ? sub(zi, bi_ld(sc, 13, lane, Bp)) : zi);
+  }
+}
+
+// q = p / (X - x), exact: q[k-1] = p[k] + x q[k]; blockIdx.y selects (N, zeta) or (NZ, zeta w)
+__global__ __launch_bounds__(64) void plonk_divlin(const Fr* N, const Fr* NZ, const Fr* sc, Fr* W,
+                                                   Fr* WZ, size_t len, size_t Bp) {
+  LANE;
+  const Fr* p = blockIdx.y ? NZ : N;
+  Fr* q = blockIdx.y ? WZ : W;
+  const Fr x = bi_ld(sc, blockIdx.y ? 12 : 11, lane, Bp);
+  Fr carry = Fr::zero();
+  for (size_t k = len - 1; k >= 1; k--) {
+    carry = add(bi_ld(p, k, lane, Bp), mul(x, carry));
+    bi_st(q, k - 1, lane, Bp, carry);
+  }
+  bi_st(q, len - 1, lane, Bp, Fr::zero());
+}
+
+static int buf(zkmi_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return ZKMI_OK;
+  if (b.p) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  if (hipMalloc(&b.p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->err = "plonk: hipMalloc(" + std::to_string(bytes) + " B) failed";
+    return ZKMI_ERR_OOM;
+  }
+  b.bytes = bytes;
+  return ZKMI_OK;
+}
+
+static Fr fr_small(uint32_t v) {
+  Fr x = Fr::zero();
+  x.v[0] = v;
+  return to_mont(x);
+}
+
+// commitment of `count` polynomials whose coefficient rows start at scal[k] (row_idx[k] maps SRS
+// power i to a row, or null): MSM over the SRS, affine, copied to out (proof-major, 64 B each)
+static int commit(zkmi_ctx* ctx, zkmi_plonk_pk* pk, int count, const Fr* const* scal,
+                  const uint32_t* const* row_idx, void* out_host_or_dev, size_t batch) {
+  const size_t Bp = pk->Bp;
+  int rc;
+  if ((rc = buf(ctx, pk->small[2], Bp * 128)) || (rc = buf(ctx, pk->small[3], Bp * 64))) return rc;
+  for (int k = 0; k < count; k++) {
+    if ((rc = msm_run(ctx, pk->srs, scal[k], row_idx ? row_idx[k] : nullptr, Bp, pk->small[2].p)))
+      return rc;
+    if ((rc = xyzz_to_affine(ctx, 1, pk->small[2].p, pk->small[3].p, Bp))) return rc;
+    // [lane] affine -> out[(lane * count + k)]
+    ZK_HIP(hipMemcpy2DAsync((char*)out_host_or_dev + (size_t)k * 64, (size_t)count * 64,
+                            pk->small[3].p, 64, 64, batch, hipMemcpyDefault, ctx->stream));
+  }
+  ZK_HIP(hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+}  // namespace zk
+
+extern "C" {
+
+void zkmi_plonk_pk_free(zkmi_ctx* ctx, zkmi_plonk_pk* pk) {
+  if (!pk) return;
+  if (ctx) {
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+  }
+  for (Fr* p : {pk->coef, pk->coset, pk->sigma, pk->omega, pk->coset_x, pk->l1, pk->zh_inv})
+    if (p) hipFree(p);
+  if (pk->chunk_idx) hipFree(pk->chunk_idx);
+  zkmi_msm_bases_free(ctx, pk->srs);
+  for (auto& b : pk->cf)
+    if (b.p) hipFree(b.p);
+  for (auto& b : pk->big)
+    if (b.p) hipFree(b.p);
+  for (auto& b : pk->small)
+    if (b.p) hipFree(b.p);
+  delete pk;
+}
+
+int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* d, zkmi_plonk_pk** out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (!d || !out) return ZKMI_ERR_ARG;
+  if (d->log_n < 4 || d->log_n > 24) {
+    ctx->err = "plonk pk: log_n out of range [4,24]";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << d->log_n, m = 4 * n;
+  if (d->n_public >= n) {
+    ctx->err = "plonk pk: more public inputs than gates";
+    return ZKMI_ERR_ARG;
+  }
+  auto* pk = new zkmi_plonk_pk();
+  pk->log_n = d->log_n;
+  pk->n_public = d->n_public;
+  pk->max_batch = d->max_batch ? d->max_batch : 64;
+  struct { Fr** dst; const void* src; size_t count; } up[7] = {
+      {&pk->coef, d->coef, 8 * n},   {&pk->coset, d->coset, 8 * m},   {&pk->sigma, d->sigma, 3 * n},
+      {&pk->omega, d->omega, n},     {&pk->coset_x, d->coset_x, m},   {&pk->l1, d->l1_coset, m},
+      {&pk->zh_inv, d->zh_inv, 4}};
+  for (auto& u : up) {
+    if (!u.src || hipMalloc((void**)u.dst, u.count * 32) != hipSuccess ||
+        hipMemcpy(*u.dst, u.src, u.count * 32, hipMemcpyDefault) != hipSuccess) {
+      ctx->err = "plonk pk: upload failed";
+      zkmi_plonk_pk_free(ctx, pk);
+      return ZKMI_ERR_HIP;
+    }
+  }
+  // scalar-row maps of the three quotient chunks: power i of chunk c -> row c (n + 2) + i of the
+  // 4n-row coefficient buffer; powers n+2 .. n+5 -> its last row (zero: deg t < 3n + 6)
+  {
+    std::vector<uint32_t> idx(3 * (n + 6));
+    for (size_t c = 0; c < 3; c++)
+      for (size_t i = 0; i < n + 6; i++)
+        idx[c * (n + 6) + i] = (uint32_t)(i < n + 2 ? c * (n + 2) + i : m - 1);
+    if (hipMalloc((void**)&pk->chunk_idx, idx.size() * 4) != hipSuccess ||
+        hipMemcpy(pk->chunk_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      zkmi_plonk_pk_free(ctx, pk);
+      return ZKMI_ERR_HIP;
+    }
+  }
+  int rc = zkmi_msm_bases_load(ctx, 1, d->srs_g1, n + 6, (int)d->window_bits, &pk->srs);
+  if (rc) {
+    zkmi_plonk_pk_free(ctx, pk);
+    return rc;
+  }
+  *out = pk;
+  return ZKMI_OK;
+}
+
+// Round 1: witness solve (the constraint system's rows are the gate columns a, b, c), blinding,
+// commitments [a], [b], [c].
+int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const void* inputs,
+                      size_t batch, const void* blind, void* commits_out, int32_t* status_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (ctx->sets[0].pending || ctx->sets[1].pending) {
+    ctx->err = "a submitted Groth16 batch is in flight; collect it first";
+    return ZKMI_ERR_ARG;
+  }
+  if (batch == 0 || batch > pk->max_batch) {
+    ctx->err = "plonk: batch must be in [1, max_batch]";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n, m = 4 * n, Bp = round_up(batch, 64);
+  if (cs->n_constraints > n || cs->n_public - 1 != pk->n_public) {
+    ctx->err = "plonk: constraint system does not match the key";
+    return ZKMI_ERR_ARG;
+  }
+  pk->batch = batch;
+  pk->Bp = Bp;
+  pk->round = 0;
+  int rc;
+  for (auto& b : pk->cf)
+    if ((rc = buf(ctx, b, (n + 8) * Bp * 32))) return rc;
+  for (auto& b : pk->big)
+    if ((rc = buf(ctx, b, m * Bp * 32))) return rc;
+  if ((rc = buf(ctx, pk->small[0], 16 * Bp * 32)) || (rc = buf(ctx, pk->small[1], 16 * Bp * 32)))
+    return rc;
+  const size_t n_in = cs->n_public - 1 + cs->n_secret, nc = cs->n_constraints;
+  // stage inputs + blinding scalars (host or device, proof-major)
+  void *in_dev = nullptr, *bl_dev = nullptr;
+  ZK_HIP(hipMalloc(&in_dev, batch * n_in * 32));
+  ZK_HIP(hipMalloc(&bl_dev, batch * 9 * 32));
+  ZK_HIP(hipMemcpyAsync(in_dev, inputs, batch * n_in * 32, hipMemcpyDefault, ctx->stream));
+  ZK_HIP(hipMemcpyAsync(bl_dev, blind, batch * 9 * 32, hipMemcpyDefault, ctx->stream));
+  // value file and gate columns: big[0] = slots (reused later), big[1..3] = a, b, c
+  if ((size_t)cs->n_slots > m) {
+    ctx->err = "plonk: value file larger than the 4n work buffer";
+    hipFree(in_dev);
+    hipFree(bl_dev);
+    return ZKMI_ERR_ARG;
+  }
+  Fr* slots = (Fr*)pk->big[0].p;
+  Fr *A = (Fr*)pk->big[1].p, *B = (Fr*)pk->big[2].p, *C = (Fr*)pk->big[3].p;
+  void* st;
+  if ((rc = ensure_scratch(ctx, 5, Bp * 4, &st))) return rc;
+  rc = transpose_in(ctx, in_dev, slots + Bp, n_in, batch, Bp, 32);
+  // the inputs in gnark's image, for PI(X) in round 3: big[5] rows 0 .. n_pub - 1 are the public ones
+  if (!rc && n_in > m) rc = ZKMI_ERR_ARG;
+  if (!rc) rc = transpose_in(ctx, in_dev, pk->big[5].p, n_in, batch, Bp, 32);
+  if (!rc) rc = rows_to_f_domain(ctx, slots + Bp, n_in, Bp);
+  if (!rc) rc = transpose_in(ctx, bl_dev, pk->small[0].p, 9, batch, Bp, 32);
+  if (!rc) rc = solve_bi(ctx, cs, slots, A, B, C, (int32_t*)st, Bp);
+  if (!rc) rc = rows_to_std_domain(ctx, A, nc, Bp);
+  if (!rc) rc = rows_to_std_domain(ctx, B, nc, Bp);
+  if (!rc) rc = rows_to_std_domain(ctx, C, nc, Bp);
+  // rows the solver does not write (padding gates) must read as zero in round 2
+  if (!rc && nc < n)
+    for (Fr* col : {A, B, C})
+      hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 64), dim3(64), 0, ctx->stream,
+                         col, nc, n, Bp);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(in_dev);
+  hipFree(bl_dev);
+  if (rc) return rc;
+  ZK_HIP(hipMemcpy(status_out, st, batch * 4, hipMemcpyDefault));
+  NttPlan* plan;
+  if ((rc = get_plan(ctx, (int)pk->log_n, &plan))) return rc;
+  const dim3 gl((unsigned)(Bp / 64));
+  // columns (rows >= nc read as zero) -> coefficients -> blinded
+  Fr* cols[3] = {A, B, C};
+  for (int k = 0; k < 3; k++) {
+    Fr* cf = (Fr*)pk->cf[k].p;
+    if ((rc = ntt_bi(ctx, plan, cols[k], cf, Bp, true, false, nc))) return rc;
+    hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, cf, n,
+                       n + 8, Bp);
+    hipLaunchKernelGGL(plonk_blind, gl, dim3(64), 0, ctx->stream, cf, n, (const Fr*)pk->small[0].p,
+                       2 * k, 2, Bp);
+  }
+  ZK_HIP(hipGetLastError());
+  const Fr* sc[3] = {(Fr*)pk->cf[0].p, (Fr*)pk->cf[1].p, (Fr*)pk->cf[2].p};
+  if ((rc = commit(ctx, pk, 3, sc, nullptr, commits_out, batch))) return rc;
+  pk->round = 1;
+  return ZKMI_OK;
+}
+
+// Round 2: beta, gamma (batch x 2 fr) -> grand product z, blinded, commitment [z].
+// The gate columns are still in big[1..3] (Lagrange values).
+int zkmi_plonk_round2(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* beta_gamma, void* commit_z_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (pk->round != 1) {
+    ctx->err = "plonk: round 2 out of order";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
+  int rc;
+  void* tmp;
+  ZK_HIP(hipMalloc(&tmp, batch * 64));
+  ZK_HIP(hipMemcpyAsync(tmp, beta_gamma, batch * 64, hipMemcpyDefault, ctx->stream));
+  Fr* ch = (Fr*)pk->small[1].p;   // rows: 0 beta, 1 gamma, 2 alpha, 3 zeta ...
+  rc = transpose_in(ctx, tmp, ch, 2, batch, Bp, 32);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (rc) return rc;
+  // the solver leaves rows >= n_constraints of the columns untouched: they must read as zero here
+  Fr *A = (Fr*)pk->big[1].p, *B = (Fr*)pk->big[2].p, *C = (Fr*)pk->big[3].p;
+  Fr *F = (Fr*)pk->big[0].p, *G = F + n * Bp, *P = G + n * Bp, *cp = P + n * Bp;   // 4n rows in all
+  const size_t chunk = 256, n_chunks = (n + chunk - 1) / chunk;
+  const unsigned gy = (unsigned)(n < 4096 ? n : 4096);
+  hipLaunchKernelGGL(plonk_fg, dim3((unsigned)(Bp / 64), gy), dim3(64), 0, ctx->stream, A, B, C,
+                     pk->sigma, pk->omega, ch, F, G, n, Bp, fr_small(5), fr_small(25));
+  hipLaunchKernelGGL(plonk_ratio, dim3((unsigned)(Bp / 64), (unsigned)n_chunks), dim3(64), 0,
+                     ctx->stream, F, G, P, cp, n, chunk, Bp);
+  hipLaunchKernelGGL(plonk_chunk_scan, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, cp,
+                     n_chunks, Bp);
+  Fr* Z = (Fr*)pk->big[4].p;
+  hipLaunchKernelGGL(plonk_z_fill, dim3((unsigned)(Bp / 64), (unsigned)n_chunks), dim3(64), 0,
+                     ctx->stream, F, cp, Z, n, chunk, Bp);
+  ZK_HIP(hipGetLastError());
+  NttPlan* plan;
+  if ((rc = get_plan(ctx, (int)pk->log_n, &plan))) return rc;
+  Fr* cz = (Fr*)pk->cf[3].p;
+  if ((rc = ntt_bi(ctx, plan, Z, cz, Bp, true, false, n))) return rc;
+  hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, cz, n,
+                     n + 8, Bp);
+  hipLaunchKernelGGL(plonk_blind, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, cz, n,
+                     (const Fr*)pk->small[0].p, 6, 3, Bp);
+  ZK_HIP(hipGetLastError());
+  const Fr* sc[1] = {cz};
+  if ((rc = commit(ctx, pk, 1, sc, nullptr, commit_z_out, batch))) return rc;
+  pk->round = 2;
+  return ZKMI_OK;
+}
+
+// Round 3: alpha (batch fr) -> quotient, commitments [t_lo], [t_mid], [t_hi].
+int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void* commits_t_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (pk->round != 2) {
+    ctx->err = "plonk: round 3 out of order";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n, m = 4 * n, Bp = pk->Bp, batch = pk->batch;
+  int rc;
+  void* tmp;
+  ZK_HIP(hipMalloc(&tmp, batch * 32));
+  ZK_HIP(hipMemcpyAsync(tmp, alpha, batch * 32, hipMemcpyDefault, ctx->stream));
+  Fr* ch = (Fr*)pk->small[1].p;
+  rc = transpose_in(ctx, tmp, ch + 2 * Bp, 1, batch, Bp, 32);   // row 2
+  hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (rc) return rc;
+  NttPlan *plan_n, *plan_m;
+  if ((rc = get_plan(ctx, (int)pk->log_n, &plan_n)) ||
+      (rc = get_plan(ctx, (int)pk->log_n + 2, &plan_m)))
+    return rc;
+  // PI(X): Lagrange values (-x_j) from the public-input rows saved in big[5] -> coefficients
+  // (big[0]) -> coset evaluations (big[5])
+  Fr* pil = (Fr*)pk->big[0].p;
+  hipLaunchKernelGGL(plonk_pi, dim3((unsigned)(Bp / 64), (unsigned)(n < 4096 ? n : 4096)),
+                     dim3(64), 0, ctx->stream, (const Fr*)pk->big[5].p, pil, (size_t)pk->n_public, n,
+                     Bp);
+  ZK_HIP(hipGetLastError());
+  Fr* pic = pil + n * Bp;
+  if ((rc = ntt_bi(ctx, plan_n, pil, pic, Bp, true, false, n))) return rc;
+  Fr *EA = (Fr*)pk->big[1].p, *EB = (Fr*)pk->big[2].p, *EC = (Fr*)pk->big[3].p,
+     *EZ = (Fr*)pk->big[4].p, *EPI = (Fr*)pk->big[5].p;
+  if ((rc = ntt_bi(ctx, plan_m, pic, EPI, Bp, false, true, n)) ||
+      (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[0].p, EA, Bp, false, true, n + 2)) ||
+      (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[1].p, EB, Bp, false, true, n + 2)) ||
+      (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[2].p, EC, Bp, false, true, n + 2)) ||
+      (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[3].p, EZ, Bp, false, true, n + 3)))
+    return rc;
+  Fr* T = (Fr*)pk->big[0].p;
+  hipLaunchKernelGGL(plonk_quotient, dim3((unsigned)(Bp / 64), (unsigned)(m < 8192 ? m : 8192)),
+                     dim3(64), 0, ctx->stream, EA, EB, EC, EZ, EPI, pk->coset, pk->coset_x, pk->l1,
+                     pk->zh_inv, ch, T, m, Bp, fr_small(5), fr_small(25));
+  ZK_HIP(hipGetLastError());
+  // coset interpolation: t coefficients in big[1]
+  Fr* ct = (Fr*)pk->big[1].p;
+  if ((rc = ntt_bi(ctx, plan_m, T, ct, Bp, true, true, m))) return rc;
+  const Fr* sc[3] = {ct, ct, ct};
+  const uint32_t* ri[3] = {pk->chunk_idx, pk->chunk_idx + (n + 6), pk->chunk_idx + 2 * (n + 6)};
+  if ((rc = commit(ctx, pk, 3, sc, ri, commits_t_out, batch))) return rc;
+  pk->round = 3;
+  return ZKMI_OK;
+}
+
+// Round 4: zeta (batch fr) -> a(zeta), b(zeta), c(zeta), S1(zeta), S2(zeta), z(zeta w)
+int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, void* evals_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (pk->round != 3) {
+    ctx->err = "plonk: round 4 out of order";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
+  int rc;
+  void* tmp;
+  ZK_HIP(hipMalloc(&tmp, batch * 64));
+  ZK_HIP(hipMemcpyAsync(tmp, zeta_zetaw, batch * 64, hipMemcpyDefault, ctx->stream));
+  Fr* pts = (Fr*)pk->small[1].p + 4 * Bp;   // rows 4, 5 of the challenge block: zeta, zeta w
+  rc = transpose_in(ctx, tmp, pts, 2, batch, Bp, 32);
+  if (rc) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    return rc;
+  }
+  EvalArgs ea{};
+  const Fr* polys[6] = {(Fr*)pk->cf[0].p, (Fr*)pk->cf[1].p, (Fr*)pk->cf[2].p, pk->coef + 5 * n,
+                        pk->coef + 6 * n, (Fr*)pk->cf[3].p};
+  const uint32_t lens[6] = {(uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n,
+                            (uint32_t)n, (uint32_t)n + 3};
+  for (int k = 0; k < 6; k++) {
+    ea.poly[k] = polys[k];
+    ea.len[k] = lens[k];
+    ea.shared[k] = (k == 3 || k == 4) ? 1 : 0;
+    ea.point_row[k] = k == 5 ? 1 : 0;
+  }
+  Fr* ev = (Fr*)pk->small[0].p;   // rows 0 .. 5 (the blinding rows are no longer needed)
+  hipLaunchKernelGGL(plonk_eval, dim3((unsigned)(Bp / 64), 6), dim3(64), 0, ctx->stream, ea,
+                     (const Fr*)pts, ev, Bp);
+  ZK_HIP(hipGetLastError());
+  void* out_dev;
+  if (hipMalloc(&out_dev, batch * 6 * 32) != hipSuccess) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    return ZKMI_ERR_OOM;
+  }
+  rc = transpose_out(ctx, ev, out_dev, 6, batch, Bp, 32);
+  if (!rc && hipMemcpyAsync(evals_out, out_dev, batch * 6 * 32, hipMemcpyDefault, ctx->stream) !=
+                 hipSuccess)
+    rc = ZKMI_ERR_HIP;
+  hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  hipFree(out_dev);
+  if (rc) return rc;
+  pk->round = 4;
+  return ZKMI_OK;
+}
+
+// Round 5: per-proof scalars of the linearisation polynomial and of the openings (batch x 14 fr,
+// see plonk_lin) -> commitments [W_zeta], [W_zeta_w]
+int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, void* commits_w_out) {
+  ZK_HIP(hipSetDevice(ctx->device));
+  if (pk->round != 4) {
+    ctx->err = "plonk: round 5 out of order";
+    return ZKMI_ERR_ARG;
+  }
+  const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
+  int rc;
+  void* tmp;
+  ZK_HIP(hipMalloc(&tmp, batch * 14 * 32));
+  ZK_HIP(hipMemcpyAsync(tmp, scalars, batch * 14 * 32, hipMemcpyDefault, ctx->stream));
+  Fr* sc = (Fr*)pk->small[0].p;
+  rc = transpose_in(ctx, tmp, sc, 14, batch, Bp, 32);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (rc) return rc;
+  const size_t L = n + 3;
+  // numerators in big[2], quotients in big[3]: 2 (n + 8) rows each (log_n >= 4)
+  Fr* N = (Fr*)pk->big[2].p;
+  Fr* NZ = N + (n + 8) * Bp;
+  Fr* W = (Fr*)pk->big[3].p;
+  Fr* WZ = W + (n + 8) * Bp;
+  hipLaunchKernelGGL(plonk_lin, dim3((unsigned)(Bp / 64), (unsigned)(L < 4096 ? L : 4096)),
+                     dim3(64), 0, ctx->stream, (const Fr*)pk->cf[0].p, (const Fr*)pk->cf[1].p,
+                     (const Fr*)pk->cf[2].p, (const Fr*)pk->cf[3].p, (const Fr*)pk->big[1].p,
+                     (const Fr*)pk->coef, (const Fr*)sc, N, NZ, n, Bp);
+  hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, W, L - 1,
+                     n + 8, Bp);
+  hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, WZ,
+                     L - 1, n + 8, Bp);
+  hipLaunchKernelGGL(plonk_divlin, dim3((unsigned)(Bp / 64), 2), dim3(64), 0, ctx->stream,
+                     (const Fr*)N, (const Fr*)NZ, (const Fr*)sc, W, WZ, L, Bp);
+  ZK_HIP(hipGetLastError());
+  const Fr* scs[2] = {W, WZ};
+  if ((rc = commit(ctx, pk, 2, scs, nullptr, commits_w_out, batch))) return rc;
+  pk->round = 0;
+  return ZKMI_OK;
+}
+
+}  // extern "C"

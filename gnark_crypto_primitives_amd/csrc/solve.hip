@@ -1,4 +1,5 @@
-// Batched R1CS witness solve: one lane per proof runs the circuit's straight-line witness program.
+// Batched R1CS witness solve: S lanes of a wavefront per proof run the circuit's witness program,
+// packed by the frontend into steps of independent operations (VLIW; S = 1 is one lane per proof).
 //
 // Replaces cs.R1CS.Solve (gnark constraint/bn254) [UPSTREAM-RECALL, SURVEY.md §3.2 step 1].  gnark
 // walks the constraints of ONE witness, solving the single unknown wire of each from its linear
@@ -28,14 +29,17 @@
 
 #include "zkmi_internal.h"
 #include "ff29.h"
+#include "ff29_asm.h"
 
 namespace zk {
 
 // products / inverses / integer value of F-domain elements kept in the packed canonical image
 __device__ __forceinline__ Fr fmul(const Fr& a, const Fr& b) {
   Fr r;
+  // the single-accumulator asm chain of ff29_asm.h: ~215 instructions instead of ~260 (the wave is
+  // alone on its SIMD: the solve is paced by its instruction count)
   pack_canonical<Fr29Params>(r.v,
-                             mul_ilp(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
+                             mul_asm(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
   return r;
 }
 __device__ __forceinline__ Fr f_one() {
@@ -51,8 +55,8 @@ __device__ Fr finv(const Fr& a) {  // a^(r-2): 0 -> 0 (gnark-crypto Element.Inve
     uint32_t e = FrParams::p(i);
     if (i == 0) e -= 2;
     for (int b = 31; b >= 0; b--) {
-      R = mul_ilp(R, R);
-      if ((e >> b) & 1) R = mul_ilp(R, A);
+      R = sqr_asm(R);
+      if ((e >> b) & 1) R = mul_asm(R, A);
     }
   }
   Fr r;
@@ -67,128 +71,159 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
   return r;
 }
 
-__global__ __launch_bounds__(256) void solve_kernel(const uint4* __restrict__ prog,
-                                                   const Fr* __restrict__ consts, Fr* slots,
-                                                   Fr* __restrict__ a, Fr* __restrict__ b,
-                                                   Fr* __restrict__ c, int32_t* __restrict__ status,
-                                                   size_t Bp, uint32_t n_ops) {
-  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t k = 0;
+// ---- VLIW solver: S sub-lanes of a wavefront per proof -----------------------------------------
+// The frontend packs independent operations of one class into steps (frontend/schedule.py); a
+// wavefront holds 64 / S proofs, lane l = (sub-lane l / (64 / S), proof l % (64 / S)), and every
+// sub-lane runs its own operand quad of the step.  Program rows are (1 + S) quads of 16 bytes: the
+// header (class, active, aux) is wave-uniform and comes through the scalar unit, the operand quad
+// is one 16-byte vector load per lane, issued one step ahead.
+//
+// Memory order: a step's operands may have been stored by OTHER lanes of the same wavefront in an
+// earlier step.  The sub-lanes of a proof are work-items of ONE wavefront, so the release /
+// acquire pair they need is a wavefront-scope fence: it pins the compiler's ordering and costs no
+// instruction, because the vector memory instructions of a wavefront reach the CU's L1 / the L2 in
+// issue order (a workgroup-scope fence here -- s_waitcnt vmcnt(0) after every step -- exposed the
+// store latency: 96 -> 7x ms per batch).
+enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV };
+
+template <int S>
+__global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict__ prog,
+                                                        const Fr* __restrict__ consts, Fr* slots,
+                                                        Fr* __restrict__ a, Fr* __restrict__ b,
+                                                        Fr* __restrict__ c,
+                                                        int32_t* __restrict__ status, size_t Bp,
+                                                        uint32_t n_rows) {
+  constexpr int PPW = 64 / S;   // proofs per wavefront
+  const uint32_t sl = threadIdx.x / PPW;   // sub-lane
+  const size_t lane = (size_t)blockIdx.x * PPW + (threadIdx.x % PPW);   // proof
   int32_t st = 0;
 #define LD(i) bi_ld(slots, (i), lane, Bp)
 #define ST(i, v) bi_st(slots, (i), lane, Bp, (v))
-  for (uint32_t pc = 0; pc < n_ops; pc++) {
-    const uint4 ins = prog[pc];
-    const uint32_t op = ins.x & 0xffu;
-    const uint32_t d = ins.y, x = ins.z, y = ins.w;
-    switch (op) {
-      case OP_ADD:
-        ST(d, add(LD(x), LD(y)));
+  const uint4* qp = prog + 1 + sl;
+  uint4 q_next = n_rows ? qp[0] : make_uint4(0, 0, 0, 0);
+  for (uint32_t r = 0; r < n_rows; r++) {
+    const uint4 hdr = prog[(size_t)r * (1 + S)];
+    const uint4 q = q_next;
+    if (r + 1 < n_rows) q_next = qp[(size_t)(r + 1) * (1 + S)];
+    const uint32_t cls = hdr.x & 0xffu;
+    const uint32_t op = q.x & 0x1fu, k = q.x >> 8;
+    const uint32_t d = q.y, x = q.z, y = q.w;
+    switch (cls) {
+      case CLS_M:
+        if (op != OP_END) {
+          const Fr va = LD(x);
+          const Fr vb = op == OP_MULC ? consts[y] : LD(y);
+          const Fr vc = fmul(va, vb);
+          ST(d, vc);
+          if (op == OP_MULABC) {
+            bi_st_nt(a, k, lane, Bp, va);
+            bi_st_nt(b, k, lane, Bp, vb);
+            bi_st_nt(c, k, lane, Bp, vc);
+          }
+        }
         break;
-      case OP_SUB:
-        ST(d, sub(LD(x), LD(y)));
+      case CLS_X:
+        if (op != OP_END) {   // d = x xor y = x + y - 2xy and the row (2x, y, 2xy)
+          const Fr va = LD(x), vb = LD(y);
+          const Fr ab = fmul(va, vb);
+          const Fr ab2 = add(ab, ab);
+          ST(d, sub(add(va, vb), ab2));
+          if (op == OP_XORABC) {   // OP_XOR: value only (PLONK lowering: rows come from OP_ABC)
+            bi_st_nt(a, k, lane, Bp, add(va, va));
+            bi_st_nt(b, k, lane, Bp, vb);
+            bi_st_nt(c, k, lane, Bp, ab2);
+          }
+        }
         break;
-      case OP_MUL:
-        ST(d, fmul(LD(x), LD(y)));
+      case CLS_A:
+        if (op != OP_END) {
+          Fr v;
+          if (op == OP_SETC) {
+            v = consts[y];
+          } else {
+            const Fr va = LD(x);
+            if (op == OP_ADD)
+              v = add(va, LD(y));
+            else if (op == OP_SUB)
+              v = sub(va, LD(y));
+            else if (op == OP_ADDC)
+              v = add(va, consts[y]);
+            else if (op == OP_NEG)
+              v = neg(va);
+            else
+              v = va;   // OP_COPY
+          }
+          ST(d, v);
+        }
         break;
-      case OP_MULC:
-        ST(d, fmul(LD(x), consts[y]));
+      case CLS_R:
+        if (op != OP_END) {
+          const Fr va = LD(d), vb = LD(x), vc = LD(y);
+          bi_st_nt(a, k, lane, Bp, va);
+          bi_st_nt(b, k, lane, Bp, vb);
+          bi_st_nt(c, k, lane, Bp, vc);
+          if ((q.x & 0x20u) && fmul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
+        }
         break;
-      case OP_ADDC:
-        ST(d, add(LD(x), consts[y]));
+      case CLS_I:
+        if (op != OP_END) {
+          const Fr va = LD(x);
+          ST(d, op == OP_DIV ? fmul(va, finv(LD(y))) : finv(va));
+        }
         break;
-      case OP_NEG:
-        ST(d, neg(LD(x)));
-        break;
-      case OP_INV:
-        ST(d, finv(LD(x)));
-        break;
-      case OP_DIV:
-        ST(d, fmul(LD(x), finv(LD(y))));
-        break;
-      case OP_SETC:
-        ST(d, consts[y]);
-        break;
-      case OP_COPY:
-        ST(d, LD(x));
-        break;
-      case OP_BITS: {
-        Fr v = f_plain(LD(x));
+      case CLS_BITS: {
+        // one instruction, quad of sub-lane 0: (dst0, src, n bits); the sub-lanes split the bits
+        const uint4 q0 = prog[(size_t)r * (1 + S) + 1];
+        const uint32_t n = q0.w, per = (n + S - 1) / S;
+        const uint32_t i0 = sl * per, i1 = i0 + per < n ? i0 + per : n;
+        const Fr v = f_plain(LD(q0.z));
         const Fr one = f_one(), zero = Fr::zero();
-        for (uint32_t i = 0; i < y; i++) {
-          const uint32_t bit = i < 256 ? (v.v[0] & 1u) : 0u;
-#pragma unroll
-          for (int l = 0; l < 7; l++) v.v[l] = (v.v[l] >> 1) | (v.v[l + 1] << 31);
-          v.v[7] >>= 1;
-          ST(d + i, bit ? one : zero);
+        for (uint32_t i = i0; i < i1; i++) {
+          const uint32_t bit = i < 256 ? (v.v[i >> 5] >> (i & 31)) & 1u : 0u;
+          ST(q0.y + i, bit ? one : zero);
         }
         break;
       }
-      case OP_BATCHINV: {
-        // rows pc+1 .. pc+n are (OP_PAIR, dst, src): dst = 1/src (0 for 0) with one inversion.
-        // dst rows double as the prefix-product scratch; dst and src slots are distinct wires.
-        const uint32_t n = d;
+      case CLS_BINV: {
+        // hdr.y pairs in the hdr.z rows that follow, S pairs per row: every sub-lane inverts its
+        // own column of pairs with one field inversion (Montgomery's trick); dst rows double as
+        // the prefix-product scratch; dst and src slots are distinct wires
+        const uint32_t nrows = hdr.z;
+        const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1 + sl;
         Fr acc = f_one();
-        for (uint32_t k = 1; k <= n; k++) {
-          const uint4 pr = prog[pc + k];
-          const Fr v = LD(pr.z);
-          ST(pr.y, acc);
+        for (uint32_t t = 0; t < nrows; t++) {
+          const uint4 p = pr[(size_t)t * (1 + S)];
+          if ((p.x & 0x1fu) != OP_PAIR) continue;
+          const Fr v = LD(p.z);
+          ST(p.y, acc);
           if (!v.is_zero()) acc = fmul(acc, v);
         }
         Fr inv = finv(acc);
-        for (uint32_t k = n; k >= 1; k--) {
-          const uint4 pr = prog[pc + k];
-          const Fr v = LD(pr.z);
+        for (uint32_t t = nrows; t-- > 0;) {
+          const uint4 p = pr[(size_t)t * (1 + S)];
+          if ((p.x & 0x1fu) != OP_PAIR) continue;
+          const Fr v = LD(p.z);
           if (v.is_zero()) {
-            ST(pr.y, Fr::zero());
+            ST(p.y, Fr::zero());
           } else {
-            const Fr res = fmul(inv, LD(pr.y));
+            const Fr res = fmul(inv, LD(p.y));
             inv = fmul(inv, v);
-            ST(pr.y, res);
+            ST(p.y, res);
           }
         }
-        pc += n;
-        break;
-      }
-      case OP_MULABC: {  // d = x * y and the row (x, y, d) in one step
-        const Fr va = LD(x), vb = LD(y);
-        const Fr vc = fmul(va, vb);
-        ST(d, vc);
-        bi_st_nt(a, k, lane, Bp, va);
-        bi_st_nt(b, k, lane, Bp, vb);
-        bi_st_nt(c, k, lane, Bp, vc);
-        k++;
-        break;
-      }
-      case OP_XORABC: {  // d = x xor y = x + y - 2xy and the row (2x, y, 2xy)
-        const Fr va = LD(x), vb = LD(y);
-        const Fr ab = fmul(va, vb);
-        const Fr ab2 = add(ab, ab);
-        ST(d, sub(add(va, vb), ab2));
-        bi_st_nt(a, k, lane, Bp, add(va, va));
-        bi_st_nt(b, k, lane, Bp, vb);
-        bi_st_nt(c, k, lane, Bp, ab2);
-        k++;
-        break;
-      }
-      case OP_ABC: {
-        const Fr va = LD(d), vb = LD(x), vc = LD(y);
-        bi_st_nt(a, k, lane, Bp, va);
-        bi_st_nt(b, k, lane, Bp, vb);
-        bi_st_nt(c, k, lane, Bp, vc);
-        if (ins.x & 0x100u) {
-          if (fmul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
-        }
-        k++;
+        r += nrows;
+        if (r + 1 < n_rows) q_next = qp[(size_t)(r + 1) * (1 + S)];
         break;
       }
       default:
         break;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 #undef LD
 #undef ST
-  status[lane] = st;
+  // a proof is unsatisfied if any of its sub-lanes saw a failing row
+  if (st) atomicMin(&status[lane], st);
 }
 
 __global__ void fill_one_row(Fr* row, size_t Bp) {
@@ -246,15 +281,33 @@ int array_to_f_domain(zkmi_ctx* ctx, Fr* a, size_t n) {
   return ZKMI_OK;
 }
 
+__global__ void zero_status(int32_t* st, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st[i] = 0;
+}
+
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
              size_t Bp) {
   hipLaunchKernelGGL(fill_one_row, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, slots, Bp);
-  // lanes per block (zkmi_cs_desc.solve_block): 64 spreads the 16 waves of a 1024-proof batch over
-  // 16 CUs, 256 packs them on 4
-  const unsigned sb = cs->solve_block ? cs->solve_block : 64;
-  const unsigned bs = (Bp % sb == 0) ? sb : 64;
-  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)(Bp / bs)), dim3(bs), 0, ctx->stream,
-                     (const uint4*)cs->program, cs->consts, slots, a, b, c, status, Bp, cs->n_ops);
+  hipLaunchKernelGGL(zero_status, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, status, Bp);
+  // one wavefront per 64 / S proofs
+  const uint32_t S = cs->lanes_per_proof;
+  const dim3 grid((unsigned)(Bp * S / 64)), block(64);
+  const uint4* prog = (const uint4*)cs->program;
+#define ZK_SOLVE(SS)                                                                          \
+  hipLaunchKernelGGL((solve_vliw_kernel<SS>), grid, block, 0, ctx->stream, prog, cs->consts, \
+                     slots, a, b, c, status, Bp, cs->n_rows)
+  switch (S) {
+    case 1: ZK_SOLVE(1); break;
+    case 2: ZK_SOLVE(2); break;
+    case 4: ZK_SOLVE(4); break;
+    case 8: ZK_SOLVE(8); break;
+    case 16: ZK_SOLVE(16); break;
+    default:
+      ctx->err = "cs: lanes_per_proof must be 1, 2, 4, 8 or 16";
+      return ZKMI_ERR_ARG;
+  }
+#undef ZK_SOLVE
   ZK_HIP(hipGetLastError());
   return ZKMI_OK;
 }

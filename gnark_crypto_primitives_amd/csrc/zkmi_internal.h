@@ -103,6 +103,9 @@ struct WinPlan {
   // for every non-empty subset m (2^k entries, entry 0 unused), 254 one-bit windows: 254 / k mixed
   // additions per (base, proof).  W = 254; bits/off are not used.
   uint8_t comb = 0;
+  // comb_signed: the comb table holds sign patterns, entry e = P_(k-1) + sum_{i<k-1} +-P_i
+  // (2^(k-1) entries per group); W = 255: window 254 is the parity correction (msm.hip)
+  uint8_t comb_signed = 0;
 };
 
 struct zkmi_msm_bases {
@@ -115,6 +118,8 @@ struct zkmi_msm_bases {
   size_t n_groups = 0;     // comb plans: ceil(n / k)
   int entries_may_be_inf = 0;  // comb plans: some subset of a group sums to the identity
   uint32_t chunk_factor = 0;   // (window, chunk) blocks in flight / wave slots; 0 = default
+  zk::G1Affine stotal1 = {};   // signed comb tables: sum of all bases (G1 / G2 by `group`)
+  zk::G2Affine stotal2 = {};
 };
 
 struct zkmi_pk {
@@ -128,8 +133,8 @@ struct zkmi_pk {
 };
 
 struct zkmi_cs {
-  uint32_t n_wires = 0, n_public = 0, n_secret = 0, n_constraints = 0, n_slots = 0, n_ops = 0,
-           n_consts = 0, solve_block = 0;
+  uint32_t n_wires = 0, n_public = 0, n_secret = 0, n_constraints = 0, n_slots = 0, n_rows = 0,
+           n_consts = 0, lanes_per_proof = 1;
   uint32_t* program = nullptr;  // device
   zk::Fr* consts = nullptr;     // device
 };
@@ -164,7 +169,7 @@ __device__ __forceinline__ void bi_st_nt(Fr* base, size_t row, size_t b, size_t 
 
 // witness-program opcodes (frontend/api.py)
 enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC,
-       OP_ABC, OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC };
+       OP_ABC, OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC, OP_XOR };
 
 #define ZK_HIP(call)                                                         \
   do {                                                                       \
@@ -209,8 +214,9 @@ int msm_bases_build(zkmi_ctx* ctx, int group, const void* bases_dev, size_t n, c
 // maps base i to its scalar row.  out_xyzz: Bp accumulators.
 // scalars_f: the scalars are in the F domain (solver output) instead of gnark's image
 WinPlan plan_shared(int c);
-WinPlan plan_comb(int k);
-void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2);
+WinPlan plan_comb(int k, bool signed_tables = true);
+void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2, bool* sg1,
+                          bool* sg2);
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
             size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr,
@@ -221,8 +227,9 @@ int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const
 // sums over the chunk partials run there too (ordered after the accumulate launch by an event; the
 // partials of consecutive MSMs alternate between two buffers), so the main stream holds nothing
 // but the digit pass and the accumulate kernel.
-int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int group, const WinPlan& plan, int count,
-                   void* const* wsums, void* const* outs, size_t Bp);
+int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int count,
+                   const zkmi_msm_bases* const* bases, void* const* wsums, void* const* outs,
+                   size_t Bp);
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n);
 

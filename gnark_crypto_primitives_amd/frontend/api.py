@@ -27,7 +27,8 @@ R = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 
 # witness-program opcodes (decoded by csrc/solve.hip and by CompiledCircuit.run_program)
 OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC, OP_ABC, \
-    OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC = range(17)
+    OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC, OP_XOR = range(18)
+# OP_XOR: OP_XORABC without its R1CS row (the PLONK lowering emits its own gate rows, scs.py)
 
 HINT_INVZERO, HINT_NBITS = 1, 2
 FIELD_BITS = 254      # bit length of r

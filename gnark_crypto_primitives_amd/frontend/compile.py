@@ -15,7 +15,7 @@ import numpy as np
 
 from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS,
                   OP_COPY, OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR,
-                  OP_SETC, OP_XORABC,
+                  OP_SETC, OP_XOR, OP_XORABC,
                   OP_SUB, R)
 
 
@@ -69,6 +69,109 @@ def from_mont_array(a: np.ndarray):
     return [x * MONT_RINV % R for x in array_to_ints(a)]
 
 
+SUB_LANE_CHOICES = (1, 2, 4, 8, 16)
+
+
+def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
+    """Scheduled (VLIW) form of a witness program: the operations packed into steps of up to S
+    independent operations of one class, S sub-lanes per proof (schedule.py).
+    ops: SSA ops in a valid order; val_wire: value -> wire (its slot forever); row_of: op index ->
+    constraint row it emits; chk: op index -> 1 when the solver must verify that row.
+    Returns (vprogram uint32 [n_rows, 1 + S, 4], n_rows, n_steps, n_slots, S, cost); row = header
+    quad (class, active, aux, 0) + S operand quads (op | chk << 5 | row_k << 8, dst slot, a, b); a
+    BATCHINV step is followed by ceil(n / S) rows of (OP_PAIR, dst, src) quads.  Temporaries are
+    recycled by step."""
+    from . import schedule as sch
+    bits_vals = {o[1]: range(o[1], o[1] + o[3]) for o in ops if o[0] == OP_BITS}
+    best = None
+    # auto: 4 sub-lanes (idle sub-lanes cost nothing: the solve is a latency chain on an
+    # otherwise empty SIMD), more only while doubling them shortens the schedule by >= 8 %
+    choices = (lanes_req,) if lanes_req else (4, 8, 16)
+    for S in choices:
+        if S not in SUB_LANE_CHOICES:
+            raise ValueError(f"lanes_per_proof must be one of {SUB_LANE_CHOICES}")
+        steps = sch.schedule(ops, bits_vals, S)
+        cost = sch.schedule_cost(steps)
+        if best is None or cost < 0.92 * best[1]:
+            best = (S, cost, steps)
+        else:
+            break
+    S, cost, steps = best
+    # ---- last use (step index) of every value
+    last = {}
+    for t, (c, idxs) in enumerate(steps):
+        for i in idxs:
+            op, dst, a, b = ops[i]
+            if op == OP_BATCHINV:
+                for q in range(1, dst + 1):
+                    last[ops[i + q][2]] = t
+            else:
+                for v in sch.reads_of(op, dst, a, b):
+                    last[v] = t
+    slot = dict(val_wire)
+    free, n_slots = [], n_wires
+    rows = []
+
+    def quad(i):
+        op, dst, a, b = ops[i]
+        if op == OP_ABC:
+            return (op | chk.get(i, 0) << 5 | row_of[i] << 8, slot[dst], slot[a], slot[b])
+        w0 = op | (row_of[i] << 8 if i in row_of else 0)
+        if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR):
+            return (w0, slot[dst], slot[a], slot[b])
+        if op in (OP_MULC, OP_ADDC):
+            return (w0, slot[dst], slot[a], b)
+        if op in (OP_NEG, OP_INV, OP_COPY):
+            return (w0, slot[dst], slot[a], 0)
+        if op == OP_SETC:
+            return (w0, slot[dst], 0, b)
+        if op == OP_BITS:
+            return (w0, slot[dst], slot[a], b)
+        raise AssertionError(op)
+
+    for t, (c, idxs) in enumerate(steps):
+        released = []
+        # destinations first get their slots (sources are all older values)
+        for i in idxs:
+            op, dst, a, b = ops[i]
+            if op in (OP_ABC, OP_BATCHINV, OP_BITS):
+                continue
+            if dst not in slot:
+                if free:
+                    slot[dst] = free.pop()
+                else:
+                    slot[dst] = n_slots
+                    n_slots += 1
+                if dst not in last:
+                    released.append(slot[dst])
+        hdr = (c, len(idxs), 0, 0)
+        if c == sch.CLS_BINV:
+            i = idxs[0]
+            npairs = ops[i][1]
+            nrows = -(-npairs // S)
+            rows.append([(c, npairs, nrows, 0)] + [(0, 0, 0, 0)] * S)
+            pairs = [(OP_PAIR, slot[ops[i + q][1]], slot[ops[i + q][2]], 0)
+                     for q in range(1, npairs + 1)]
+            for r in range(nrows):
+                chunk = pairs[r * S:(r + 1) * S]
+                rows.append([(sch.CLS_BINV | 0x100, len(chunk), 0, 0)] + chunk +
+                            [(0, 0, 0, 0)] * (S - len(chunk)))
+        else:
+            quads = [quad(i) for i in idxs]
+            rows.append([hdr] + quads + [(0, 0, 0, 0)] * (S - len(quads)))
+        # temporaries whose last reader is this step return to the pool for LATER steps
+        for i in idxs:
+            op, dst, a, b = ops[i]
+            srcs = [ops[i + q][2] for q in range(1, dst + 1)] if op == OP_BATCHINV \
+                else sch.reads_of(op, dst, a, b)
+            for v in set(srcs):
+                if last.get(v) == t and v not in val_wire and v in slot:
+                    released.append(slot.pop(v))
+        free.extend(released)
+    vprogram = np.array(rows, dtype=np.uint32).reshape(len(rows), 1 + S, 4)
+    return vprogram, len(rows), len(steps), n_slots, S, cost
+
+
 class CompiledCircuit:
     """What gnark calls constraint.ConstraintSystem, for this framework.
 
@@ -78,8 +181,9 @@ class CompiledCircuit:
     value slots; slot i < n_wires *is* wire i.
     """
 
-    def __init__(self, api: API, layout):
+    def __init__(self, api: API, layout, lanes_per_proof=0):
         self.layout = layout                      # [(name, n|None, public?)]
+        self._lanes_req = lanes_per_proof
         self.n_wires = api.n_wires
         self.n_public = api.n_public              # includes the ONE wire
         self.n_secret = api.n_secret
@@ -218,6 +322,101 @@ class CompiledCircuit:
         self.program = prog
         self.n_slots = n_slots
         self.n_ops = len(ops)
+        self._build_vprogram(api, ops)
+
+    # ------------------------------------------------------------------ VLIW witness program
+    def _build_vprogram(self, api, ops):
+        """The program the GPU solver runs (csrc/solve.hip): see ``build_vprogram``."""
+        self._ops = ops                       # post-DCE SSA ops: the PLONK lowering starts here
+        self._val_wire = dict(api.val_wire)
+        row_of, k = {}, 0                     # constraint row of every row-emitting op
+        for i, o in enumerate(ops):
+            if o[0] in (OP_ABC, OP_MULABC, OP_XORABC):
+                row_of[i] = k
+                k += 1
+        chk = {i: (1 if api.constraints[r][5] else 0) for i, r in row_of.items()
+               if ops[i][0] == OP_ABC}
+        self._row_check = [bool(api.constraints[r][5]) for r in range(k)]
+        (self.vprogram, self.v_n_rows, self.v_n_steps, self.v_n_slots, self.lanes_per_proof,
+         self.schedule_cost) = build_vprogram(ops, api.val_wire, row_of, chk, self.n_wires,
+                                              self._lanes_req)
+
+    def run_vprogram(self, inputs):
+        """Evaluate ``vprogram`` with Python integers exactly as the GPU kernel does (all reads of
+        a step before its writes; sub-lanes in index order) -- the CPU check of the scheduler and
+        of the step-wise slot recycling.  Returns (wires, a, b, c)."""
+        from . import schedule as sch
+        if len(inputs) != self.n_inputs:
+            raise ValueError(f"expected {self.n_inputs} inputs, got {len(inputs)}")
+        s = [0] * self.v_n_slots
+        s[0] = 1
+        for i, v in enumerate(inputs):
+            s[1 + i] = int(v) % R
+        nc = self.n_constraints
+        a_, b_, c_ = [None] * nc, [None] * nc, [None] * nc
+        C = self.consts
+        self.last_status = 0
+        rows = self.vprogram.tolist()
+        r = 0
+        while r < len(rows):
+            hdr, quads = rows[r][0], rows[r][1:]
+            cls = hdr[0] & 0xff
+            r += 1
+            if cls == sch.CLS_BINV:
+                for _ in range(hdr[2]):
+                    for w0, d, x, _y in rows[r][1:]:
+                        if w0 & 0x1f == OP_PAIR:
+                            s[d] = pow(s[x], R - 2, R)
+                    r += 1
+                continue
+            writes = []
+            for w0, d, x, y in quads:
+                op, chk, k = w0 & 0x1f, (w0 >> 5) & 1, w0 >> 8
+                if op == OP_END:
+                    continue
+                if op == OP_MUL:
+                    writes.append((d, s[x] * s[y] % R))
+                elif op == OP_MULC:
+                    writes.append((d, s[x] * C[y] % R))
+                elif op == OP_MULABC:
+                    v = s[x] * s[y] % R
+                    a_[k], b_[k], c_[k] = s[x], s[y], v
+                    writes.append((d, v))
+                elif op == OP_XORABC:
+                    ab2 = 2 * s[x] * s[y] % R
+                    a_[k], b_[k], c_[k] = 2 * s[x] % R, s[y], ab2
+                    writes.append((d, (s[x] + s[y] - ab2) % R))
+                elif op == OP_XOR:
+                    writes.append((d, (s[x] + s[y] - 2 * s[x] * s[y]) % R))
+                elif op == OP_ADD:
+                    writes.append((d, (s[x] + s[y]) % R))
+                elif op == OP_SUB:
+                    writes.append((d, (s[x] - s[y]) % R))
+                elif op == OP_ADDC:
+                    writes.append((d, (s[x] + C[y]) % R))
+                elif op == OP_NEG:
+                    writes.append((d, (-s[x]) % R))
+                elif op == OP_COPY:
+                    writes.append((d, s[x]))
+                elif op == OP_SETC:
+                    writes.append((d, C[y]))
+                elif op == OP_INV:
+                    writes.append((d, pow(s[x], R - 2, R)))
+                elif op == OP_DIV:
+                    writes.append((d, s[x] * pow(s[y], R - 2, R) % R))
+                elif op == OP_ABC:
+                    a_[k], b_[k], c_[k] = s[d], s[x], s[y]
+                    if chk and s[d] * s[x] % R != s[y]:
+                        self.last_status = -5
+                elif op == OP_BITS:
+                    v = s[x]
+                    for j in range(y):
+                        writes.append((d + j, (v >> j) & 1))
+                else:
+                    raise AssertionError(op)
+            for d, v in writes:
+                s[d] = v
+        return s[:self.n_wires], a_, b_, c_
 
     # ------------------------------------------------------------------ CPU evaluation
     def run_program(self, inputs):
@@ -316,8 +515,10 @@ class CompiledCircuit:
         return h.hexdigest()[:16]
 
 
-def compile_circuit(circuit) -> CompiledCircuit:
-    """``frontend.Compile(field, r1cs.NewBuilder, circuit)`` for BN254's scalar field."""
+def compile_circuit(circuit, lanes_per_proof: int = 0) -> CompiledCircuit:
+    """``frontend.Compile(field, r1cs.NewBuilder, circuit)`` for BN254's scalar field.
+    lanes_per_proof: sub-lanes of the GPU solver per proof (1, 2, 4, 8, 16; 0 = chosen from the
+    schedule lengths)."""
     api = API()
     fields = _fields(circuit)
     layout = []
@@ -333,4 +534,4 @@ def compile_circuit(circuit) -> CompiledCircuit:
                 setattr(circuit, name, [mk(f"{name}[{i}]") for i in range(f.n)])
             layout.append((name, f.n, want_public))
     circuit.define(api)
-    return CompiledCircuit(api, layout)
+    return CompiledCircuit(api, layout, lanes_per_proof)

@@ -193,3 +193,155 @@ def witness_to_inputs(buf: bytes) -> np.ndarray:
     """witness bytes -> [n_inputs, 4] Montgomery limbs for Prover.prove"""
     vals, _ = witness_from_bytes(buf)
     return ints_to_array([v * _MONT_R % R for v in vals])
+
+
+# ---- Groth16 keys (SURVEY.md §8f-1, second slice) ----------------------------------------------------
+# gnark backend/groth16/bn254/marshal.go, restated from memory [UPSTREAM-RECALL; parity unpinned:
+# nothing importable offline can confirm a byte of it].  ProvingKey.WriteRawTo:
+#   fft.Domain.WriteTo   uint64 cardinality | fr cardinalityInv | fr generator | fr generatorInv |
+#                        fr frMultiplicativeGen | fr frMultiplicativeGenInv | uint8 withPrecompute
+#   then, through gnark-crypto's Encoder (big-endian; a slice = uint32 length + elements; points
+#   uncompressed under WriteRawTo):
+#   G1.Alpha, G1.Beta, G1.Delta, G1.A[], G1.B[], G1.Z[], G1.K[], G2.Beta, G2.Delta, G2.B[],
+#   uint64 nbWires, uint64 NbInfinityA, uint64 NbInfinityB, InfinityA[] (uint32 length + one byte per
+#   bool), InfinityB[], uint32 number of commitment keys (0 for the circuits of this repository).
+# VerifyingKey.WriteRawTo: G1.Alpha, G1.Beta, G2.Beta, G2.Gamma, G1.Delta, G2.Delta, G1.K[] (uint32
+#   length + points), uint32 number of commitment-committed lists (0), uint32 commitment keys (0).
+def _fr_plain(limbs4):
+    return array_to_ints(np.asarray(limbs4, dtype=np.uint64).reshape(1, 4))[0] * _MONT_R_INV % R
+
+
+def _domain_bytes(log_n: int) -> bytes:
+    n = 1 << log_n
+    gen = pow(pow(5, (R - 1) >> 28, R), 1 << (28 - log_n), R)
+    fr = lambda v: (v % R).to_bytes(32, "big")
+    return (struct.pack(">Q", n) + fr(pow(n, R - 2, R)) + fr(gen) + fr(pow(gen, R - 2, R)) +
+            fr(5) + fr(pow(5, R - 2, R)) + b"\x00")
+
+
+def _read_domain(buf, o):
+    n, = struct.unpack_from(">Q", buf, o)
+    if n == 0 or n & (n - 1):
+        raise ValueError("domain cardinality is not a power of two")
+    log_n = n.bit_length() - 1
+    want = _domain_bytes(log_n)
+    if buf[o:o + len(want) - 1] != want[:-1]:
+        raise ValueError("fft.Domain constants do not match BN254's")
+    return log_n, o + len(want)
+
+
+def _pts(arr, enc):
+    arr = np.asarray(arr, dtype=np.uint64)
+    return struct.pack(">I", arr.shape[0]) + b"".join(enc(p, compressed=False) for p in arr)
+
+
+def _read_pts(buf, o, size, dec, width):
+    n, = struct.unpack_from(">I", buf, o)
+    o += 4
+    if o + n * size > len(buf):
+        raise ValueError("truncated point slice")
+    out = np.zeros((n, width), dtype=np.uint64)
+    for i in range(n):
+        out[i] = dec(buf[o + i * size:o + (i + 1) * size])
+    return out, o + n * size
+
+
+def proving_key_to_bytes(pk) -> bytes:
+    """groth16.ProvingKey (this package's, gnark's memory image) -> ProvingKey.WriteRawTo bytes."""
+    inf_a, inf_b = pk.infinity_maps()
+    g1 = lambda p: g1_to_bytes(p, compressed=False)
+    g2 = lambda p: g2_to_bytes(p, compressed=False)
+    out = [_domain_bytes(pk.log_n), g1(pk.g1_alpha), g1(pk.g1_beta), g1(pk.g1_delta),
+           _pts(pk.g1_a, g1_to_bytes), _pts(pk.g1_b, g1_to_bytes), _pts(pk.g1_z, g1_to_bytes),
+           _pts(pk.g1_k, g1_to_bytes), g2(pk.g2_beta), g2(pk.g2_delta), _pts(pk.g2_b, g2_to_bytes),
+           struct.pack(">QQQ", pk.n_wires, int(inf_a.sum()), int(inf_b.sum())),
+           struct.pack(">I", len(inf_a)) + inf_a.tobytes(),
+           struct.pack(">I", len(inf_b)) + inf_b.tobytes(), struct.pack(">I", 0)]
+    return b"".join(out)
+
+
+def proving_key_from_bytes(buf: bytes, n_public: int):
+    """-> groth16.ProvingKey.  ``n_public`` (wires incl. ONE) is not part of gnark's file: G1.K holds
+    the private wires in order, so k_wire = n_public .. n_wires - 1."""
+    from .groth16 import ProvingKey
+    pk = ProvingKey()
+    pk.log_n, o = _read_domain(buf, 0)
+    pk.g1_alpha, pk.g1_beta, pk.g1_delta = (g1_from_bytes(buf[o + 64 * i:o + 64 * i + 64])
+                                            for i in range(3))
+    o += 192
+    pk.g1_a, o = _read_pts(buf, o, 64, g1_from_bytes, 8)
+    pk.g1_b, o = _read_pts(buf, o, 64, g1_from_bytes, 8)
+    pk.g1_z, o = _read_pts(buf, o, 64, g1_from_bytes, 8)
+    pk.g1_k, o = _read_pts(buf, o, 64, g1_from_bytes, 8)
+    pk.g2_beta, pk.g2_delta = g2_from_bytes(buf[o:o + 128]), g2_from_bytes(buf[o + 128:o + 256])
+    o += 256
+    pk.g2_b, o = _read_pts(buf, o, 128, g2_from_bytes, 16)
+    n_wires, n_inf_a, n_inf_b = struct.unpack_from(">QQQ", buf, o)
+    o += 24
+    maps = []
+    for want in (n_inf_a, n_inf_b):
+        n, = struct.unpack_from(">I", buf, o)
+        m = np.frombuffer(buf, dtype=np.uint8, count=n, offset=o + 4)
+        o += 4 + n
+        if n != n_wires or int(m.sum()) != want or (m > 1).any():
+            raise ValueError("infinity map does not match nbWires / NbInfinity")
+        maps.append(m)
+    n_ck, = struct.unpack_from(">I", buf, o)
+    if n_ck:
+        raise ValueError("proving keys with commitment keys are not supported")
+    pk.n_wires = int(n_wires)
+    pk.a_wire = np.nonzero(maps[0] == 0)[0].astype(np.uint32)
+    pk.b_wire = np.nonzero(maps[1] == 0)[0].astype(np.uint32)
+    pk.k_wire = np.arange(n_public, n_wires, dtype=np.uint32)
+    if (len(pk.a_wire), len(pk.b_wire), len(pk.k_wire)) != (len(pk.g1_a), len(pk.g1_b), len(pk.g1_k)) \
+            or len(pk.g2_b) != len(pk.g1_b) or len(pk.g1_z) != (1 << pk.log_n) - 1:
+        raise ValueError("point counts do not match the infinity maps / domain")
+    return pk
+
+
+def verifying_key_to_bytes(vk, g1_beta, g1_delta) -> bytes:
+    """gnark's VerifyingKey also carries G1.Beta and G1.Delta (this package's does not need them:
+    pass the proving key's)."""
+    g1 = lambda p: g1_to_bytes(p, compressed=False)
+    g2 = lambda p: g2_to_bytes(p, compressed=False)
+    return b"".join([g1(vk.g1_alpha), g1(g1_beta), g2(vk.g2_beta), g2(vk.g2_gamma), g1(g1_delta),
+                     g2(vk.g2_delta), _pts(vk.g1_k, g1_to_bytes), struct.pack(">II", 0, 0)])
+
+
+def verifying_key_from_bytes(buf: bytes):
+    from .groth16 import VerifyingKey
+    vk = VerifyingKey()
+    o = 0
+    vk.g1_alpha = g1_from_bytes(buf[o:o + 64]); o += 64
+    o += 64                                              # G1.Beta
+    vk.g2_beta = g2_from_bytes(buf[o:o + 128]); o += 128
+    vk.g2_gamma = g2_from_bytes(buf[o:o + 128]); o += 128
+    o += 64                                              # G1.Delta
+    vk.g2_delta = g2_from_bytes(buf[o:o + 128]); o += 128
+    vk.g1_k, o = _read_pts(buf, o, 64, g1_from_bytes, 8)
+    a, b = struct.unpack_from(">II", buf, o)
+    if a or b:
+        raise ValueError("verifying keys with commitments are not supported")
+    return vk
+
+
+# gnark's R1CS.WriteTo is a CBOR encoding of the constraint system's internal tables (blueprints,
+# packed instructions, coefficient table, level partition): it is produced and consumed by gnark's
+# own solver, which a gnark-side caller keeps (zkmi_prove_witness_batch, INTEGRATION.md), so it is
+# not restated here.
+def save_key(path: str, pk, vk=None):
+    """Proving key (and verifying key) in gnark's raw formats, one file each."""
+    with open(path, "wb") as f:
+        f.write(proving_key_to_bytes(pk))
+    if vk is not None:
+        with open(path + ".vk", "wb") as f:
+            f.write(verifying_key_to_bytes(vk, pk.g1_beta, pk.g1_delta))
+
+
+def load_key(path: str, n_public: int):
+    pk = proving_key_from_bytes(open(path, "rb").read(), n_public)
+    try:
+        vk = verifying_key_from_bytes(open(path + ".vk", "rb").read())
+    except OSError:
+        vk = None
+    return pk, vk

@@ -164,18 +164,18 @@ class Prover:
 
     def __init__(self, ctx: _lib.Context, cc: CompiledCircuit, pk: ProvingKey,
                  window_bits_g1: int = 0, window_bits_g2: int = 0, *, max_batch: int = 0,
-                 table_budget_bytes: int = 0, msm_chunk_factor: int = 0, solve_block: int = 0,
+                 table_budget_bytes: int = 0, msm_chunk_factor: int = 0,
                  gnark_key_layout: bool = False):
-        """max_batch / table_budget_bytes / msm_chunk_factor / solve_block: zkmi_pk_desc /
-        zkmi_cs_desc plan fields (0 = default).  gnark_key_layout: describe the key the way
+        """max_batch / table_budget_bytes / msm_chunk_factor: zkmi_pk_desc plan fields
+        (0 = default).  gnark_key_layout: describe the key the way
         gnark's ProvingKey does (InfinityA / InfinityB byte maps + nbPublic) instead of wire-index
         arrays; the loaded key is the same."""
         self.ctx, self.cc, self.pk = ctx, cc, pk
         self.n_inputs = cc.n_inputs
         self._consts = to_mont_array(cc.consts) if cc.consts else np.zeros((0, 4), np.uint64)
-        prog = self._prog = np.ascontiguousarray(cc.program, dtype=np.uint32)
-        cd = _lib.CsDesc(cc.n_wires, cc.n_public, cc.n_secret, cc.n_constraints, cc.n_slots,
-                         cc.n_ops, len(cc.consts), solve_block, prog.ctypes.data,
+        prog = self._prog = np.ascontiguousarray(cc.vprogram, dtype=np.uint32)
+        cd = _lib.CsDesc(cc.n_wires, cc.n_public, cc.n_secret, cc.n_constraints, cc.v_n_slots,
+                         cc.v_n_rows, len(cc.consts), cc.lanes_per_proof, prog.ctypes.data,
                          self._consts.ctypes.data)
         self.cs_h = ctx.cs_load(cd)
         self._keep = [np.ascontiguousarray(x) for x in
@@ -194,7 +194,7 @@ class Prover:
                          pk.g1_z.shape[0], *ptrs, window_bits_g1, window_bits_g2,
                          inf_a.ctypes.data if inf_a is not None else None,
                          inf_b.ctypes.data if inf_b is not None else None, n_public,
-                         max_batch, table_budget_bytes, cc.n_slots, msm_chunk_factor)
+                         max_batch, table_budget_bytes, cc.v_n_slots, msm_chunk_factor)
         self.pk_h = ctx.pk_load(pd)
 
     def close(self):

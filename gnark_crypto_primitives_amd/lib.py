@@ -33,8 +33,8 @@ class PkDesc(C.Structure):
 
 class CsDesc(C.Structure):
     _fields_ = [("n_wires", C.c_uint32), ("n_public", C.c_uint32), ("n_secret", C.c_uint32),
-                ("n_constraints", C.c_uint32), ("n_slots", C.c_uint32), ("n_ops", C.c_uint32),
-                ("n_consts", C.c_uint32), ("solve_block", C.c_uint32), ("program", C.c_void_p),
+                ("n_constraints", C.c_uint32), ("n_slots", C.c_uint32), ("n_rows", C.c_uint32),
+                ("n_consts", C.c_uint32), ("lanes_per_proof", C.c_uint32), ("program", C.c_void_p),
                 ("consts", C.c_void_p)]
 
 

@@ -150,13 +150,17 @@ void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk);
 int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
 
 /* -- constraint system (witness program) ----------------------------------------------------- */
-/* What cs.R1CS.Solve needs, in the straight-line form produced by
- * gnark_crypto_primitives_amd.frontend.compile_circuit. */
+/* What cs.R1CS.Solve needs, in the scheduled form produced by
+ * gnark_crypto_primitives_amd.frontend.compile_circuit: the circuit's field
+ * operations packed into steps of up to `lanes_per_proof` independent operations of one class;
+ * the GPU runs a step with that many lanes of a wavefront per proof.
+ *   program: n_rows x (1 + lanes_per_proof) x 4 words.  Row = header (class, active, aux, 0) +
+ *   one operand quad per sub-lane (op | check << 5 | constraint_row << 8, dst slot, a, b). */
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
-  uint32_t n_slots, n_ops, n_consts;
-  uint32_t solve_block; /* lanes per solver workgroup: 64 (default, 0), 128 or 256 */
-  const uint32_t* program; /* (n_ops + 1) x 4 words */
+  uint32_t n_slots, n_rows, n_consts;
+  uint32_t lanes_per_proof; /* 1, 2, 4, 8 or 16 */
+  const uint32_t* program;
   const void* consts;      /* n_consts fr elements, Montgomery */
 } zkmi_cs_desc;
 int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* desc, zkmi_cs** out);
@@ -205,6 +209,46 @@ int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires
 int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                       size_t batch, const void* rs);
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
+
+/* -- PLONK (BASELINE config 5 names this backend) ----------------------------------------------- */
+/* Stands in for plonk.Prove of gnark backend/plonk/bn254 [UPSTREAM-RECALL]: KZG commitments over
+ * the SRS, blinded wire polynomials, permutation grand product, quotient on the coset 5<w_4n>
+ * split in three, linearisation and two openings.  The Fiat-Shamir hashing stays on the host, as
+ * in gnark, between five round calls; protocol and transcript: DESIGN.md (parity unpinned: the
+ * reference holds no PLONK vector).  All arrays: fr in gnark's Montgomery image; batch arrays are
+ * proof-major; host or device pointers. */
+typedef struct zkmi_plonk_pk zkmi_plonk_pk;
+typedef struct {
+  uint32_t log_n;          /* domain 2^log_n >= number of gates, 4 .. 24 */
+  uint32_t n_public;       /* public inputs (without ONE): the first n_public gates */
+  const void* coef;        /* 8 x n: qL, qR, qO, qM, qC, S1, S2, S3 in coefficient form */
+  const void* coset;       /* 8 x 4n: the same polynomials on the coset 5 <w_4n>, natural order */
+  const void* sigma;       /* 3 x n: S1, S2, S3 values on the domain (k_c w^r of the image position) */
+  const void* omega;       /* n: w^i */
+  const void* coset_x;     /* 4n: 5 w_4n^j */
+  const void* l1_coset;    /* 4n: L_1 on the coset */
+  const void* zh_inv;      /* 4: 1 / Z_H on the coset (period 4) */
+  const void* srs_g1;      /* n + 6 G1 affine points: [tau^i]_1 */
+  uint32_t window_bits;    /* MSM table plan of the SRS, as zkmi_msm_bases_load */
+  uint32_t max_batch;      /* 0 = 64 */
+} zkmi_plonk_pk_desc;
+int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* desc, zkmi_plonk_pk** out);
+void zkmi_plonk_pk_free(zkmi_ctx* ctx, zkmi_plonk_pk* pk);
+/* Round 1: witness solve (cs: the circuit's gate rows, frontend/scs.py), blinding (blind: batch x 9
+ * fr: b1 X + b2 for a, b, c and b7 X^2 + b8 X + b9 for z), commits_out: batch x 3 G1 ([a] [b] [c]). */
+int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const void* inputs,
+                      size_t batch, const void* blind, void* commits_out, int32_t* status_out);
+/* Round 2: beta_gamma: batch x 2 fr; commit_z_out: batch G1. */
+int zkmi_plonk_round2(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* beta_gamma, void* commit_z_out);
+/* Round 3: alpha: batch fr; commits_t_out: batch x 3 G1 ([t_lo] [t_mid] [t_hi], n + 2 coefficients each). */
+int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void* commits_t_out);
+/* Round 4: zeta_zetaw: batch x 2 fr (zeta, zeta w); evals_out: batch x 6 fr: a, b, c, S1, S2 at zeta,
+ * z at zeta w. */
+int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, void* evals_out);
+/* Round 5: scalars: batch x 14 fr (coefficients of the linearisation polynomial: qM, qL, qR, qO, S3,
+ * z, t_lo, t_mid, t_hi; its constant term minus sum v^i e_i; v; zeta; zeta w; z(zeta w));
+ * commits_w_out: batch x 2 G1 ([W_zeta] [W_zeta_w]). */
+int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, void* commits_w_out);
 
 /* Per-stage device time of the last zkmi_prove_collect / zkmi_prove_batch in milliseconds, from
  * HIP events on the library's streams: [0] solve (stage 1, second stream), [1] quotient (NTTs +

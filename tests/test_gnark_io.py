@@ -57,3 +57,44 @@ def test_proof_and_witness_roundtrip():
         else True
     with pytest.raises(ValueError):
         gnark_io.witness_from_bytes(w[:-1])
+
+
+def test_proving_and_verifying_key_round_trip(tmp_path):
+    """ProvingKey.WriteRawTo / VerifyingKey.WriteRawTo layouts [UPSTREAM-RECALL, parity unpinned]:
+    write -> read returns the same key (points, infinity maps -> wire indices), a corrupted
+    infinity map or a truncated slice is refused."""
+    import struct
+
+    import pytest
+
+    from gnark_crypto_primitives_amd import circuits, groth16
+    from gnark_crypto_primitives_amd.frontend import compile_circuit
+    from oracle import cref
+    from tests import helpers as H
+    cc = compile_circuit(circuits.PoseidonCircuit())
+    mul = lambda g, s: cref.batch_mul(g, H.g1_gen_mont() if g == 1 else H.g2_gen_mont(), s)
+    pk, vk, _ = groth16.setup(cc, 5, mul)
+    blob = gnark_io.proving_key_to_bytes(pk)
+    n_pts = len(pk.g1_a) + len(pk.g1_b) + len(pk.g1_z) + len(pk.g1_k) + 3
+    assert len(blob) == (8 + 5 * 32 + 1) + 64 * n_pts + 128 * (len(pk.g2_b) + 2) + 5 * 4 + 24 + \
+        2 * (4 + pk.n_wires) + 4
+    back = gnark_io.proving_key_from_bytes(blob, cc.n_public)
+    for name in ("a_wire", "b_wire", "k_wire", "g1_a", "g1_b", "g1_k", "g1_z", "g2_b", "g1_alpha",
+                 "g1_beta", "g1_delta", "g2_beta", "g2_delta"):
+        assert np.array_equal(getattr(back, name), getattr(pk, name)), name
+    assert (back.log_n, back.n_wires) == (pk.log_n, pk.n_wires)
+    vblob = gnark_io.verifying_key_to_bytes(vk, pk.g1_beta, pk.g1_delta)
+    vback = gnark_io.verifying_key_from_bytes(vblob)
+    for name in ("g1_alpha", "g2_beta", "g2_gamma", "g2_delta", "g1_k"):
+        assert np.array_equal(getattr(vback, name), getattr(vk, name)), name
+    # files
+    gnark_io.save_key(str(tmp_path / "pk.bin"), pk, vk)
+    pk2, vk2 = gnark_io.load_key(str(tmp_path / "pk.bin"), cc.n_public)
+    assert np.array_equal(pk2.g1_z, pk.g1_z) and np.array_equal(vk2.g1_k, vk.g1_k)
+    # corruption
+    bad = bytearray(blob)
+    bad[-4 - (4 + pk.n_wires) - 1] ^= 1                # flips the last InfinityA flag
+    with pytest.raises(ValueError):
+        gnark_io.proving_key_from_bytes(bytes(bad), cc.n_public)
+    with pytest.raises((ValueError, struct.error)):
+        gnark_io.proving_key_from_bytes(blob[:1000], cc.n_public)

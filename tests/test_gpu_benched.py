@@ -53,7 +53,7 @@ def test_arbo160_auto_plan_pipelined_vs_oracle(zk_ctx):
     info = zk_ctx.pk_info(prover.pk_h)
     # the benched plan: comb tables for both groups (k depends on the free HBM of the box)
     assert info["g1_comb_k"] >= 16 and info["g2_comb_k"] >= 16, info
-    assert info["g1_windows"] == 254
+    assert info["g1_windows"] == 255         # 254 sign-pattern windows + the parity correction
     rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
     rng = random.Random(2024)
     try:
@@ -75,10 +75,12 @@ def test_arbo160_auto_plan_pipelined_vs_oracle(zk_ctx):
         prover.close()
 
 
-@pytest.mark.parametrize("group,n,wb", [(1, 65535, 218), (2, 27059, 219)])
+@pytest.mark.parametrize("group,n,wb", [(1, 65535, 218), (2, 27059, 219), (1, 65535, 319),
+                                        (2, 27059, 320)])
 def test_msm_comb_plan_full_size_vs_oracle(zk_ctx, group, n, wb):
-    """zkmi_msm_batch on the quotient-sized base set under the comb plan the bench's key gets
-    (k = 18 for G1, 19 for G2), 70 scalar vectors (two wavefronts, one ragged): unit vector, short
+    """zkmi_msm_batch on the quotient-sized base set under the comb plans the bench's key gets
+    (sign-pattern tables, k = 19 for G1 and 20 for G2: 300 + k; the unsigned k = 18 / 19 tables of
+    round 1: 200 + k), 70 scalar vectors (two wavefronts, one ragged): unit vector, short
     support, all-zero, all r - 1, and uniformly random vectors against the oracle's Pippenger."""
     from oracle import cref
     r = random.Random(wb)
@@ -107,8 +109,9 @@ def test_msm_comb_plan_full_size_vs_oracle(zk_ctx, group, n, wb):
         assert np.array_equal(res[p], cref.msm(group, bases, sc[p], c=13)), p
 
 
+@pytest.mark.parametrize("signed_tables", [0, 1])
 @pytest.mark.parametrize("group", [1, 2])
-def test_msm_comb_cancelling_groups_at_scale(zk_ctx, group):
+def test_msm_comb_cancelling_groups_at_scale(zk_ctx, group, signed_tables):
     """Comb groups that contain P and -P (and a repeated base): some subset sums are the identity,
     so the key gets msm_accumulate_comb<F, true> (the variant that tests gathered entries for
     infinity).  4096 bases, k = 12, 200 proofs, every result against the oracle."""
@@ -134,7 +137,14 @@ def test_msm_comb_cancelling_groups_at_scale(zk_ctx, group):
     for g in range(0, n // k, 3):                      # every third group: bases 1 = -base 0,
         bases[g * k + 1] = neg_point(bases[g * k])     # base 5 = base 4 (doubling inside the table)
         bases[g * k + 5] = bases[g * k + 4]
-    h = zk_ctx.msm_bases_load(group, bases, n, 200 + k)
+    # sign-pattern tables: an entry is the identity when the top base equals a signed sum of the
+    # others; group 1: P_11 = P_0 - P_1 + ... - P_9 + P_10 (one pattern sums to the identity)
+    if signed_tables:
+        acc = bases[k].copy()
+        for i in range(1, k - 1):
+            acc = cref.point_add(group, acc, bases[k + i] if i % 2 == 0 else neg_point(bases[k + i]))
+        bases[2 * k - 1] = neg_point(acc)      # -(P_0 - P_1 + ...): the complement pattern cancels
+    h = zk_ctx.msm_bases_load(group, bases, n, (300 if signed_tables else 200) + k)
     sc = _rand_fr_array(rng, (batch, n))
     sc[0] = H.to_mont_array([1])[0]                     # all ones: every group index = all bits set
     sc[1] = 0

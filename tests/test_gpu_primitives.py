@@ -59,7 +59,11 @@ def test_h(zk_ctx, cref, log_n):
                                  # 100 + c: one shared table per base, per-window accumulators
                                  (1, 104), (37, 105), (200, 107), (64, 113), (90, 116), (300, 0),
                                  # 200 + k: comb tables over groups of k bases, one-bit windows
-                                 (1, 203), (37, 205), (200, 208), (90, 212), (33, 216)])
+                                 (1, 203), (37, 205), (200, 208), (90, 212), (33, 216),
+                                 # 300 + k: sign-pattern comb tables (2^(k-1) entries per group,
+                                 # the auto plan's layout), incl. a lone base and ragged last groups
+                                 (1, 303), (2, 303), (37, 305), (200, 308), (90, 313), (33, 317),
+                                 (64, 321)])
 def test_msm(zk_ctx, cref, group, n, c):
     r = H.rng(300 + n + group)
     gen = H.g1_gen_mont() if group == 1 else H.g2_gen_mont()
@@ -99,7 +103,7 @@ def test_field_mul_bench_reports(zk_ctx):
     assert rate > 1e9
 
 
-@pytest.mark.parametrize("c", [6, 106, 207])
+@pytest.mark.parametrize("c", [6, 106, 207, 307])
 def test_msm_edge_cases(zk_ctx, cref, c):
     """Infinity among the bases, extreme scalars (0, 1, r-1, r-2, 2^253), batch sizes around the
     64-lane padding (1, 63, 64, 65), and an empty batch -- both table layouts."""

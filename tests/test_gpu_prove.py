@@ -107,7 +107,7 @@ def test_invalid_witness_status(zk_ctx, poseidon_setup):
 
 @pytest.mark.parametrize("levels,populated,wbits", [(8, 3, (7, 5)), (24, 0, (7, 5)),
                                                     (8, 5, (109, 106)), (12, 2, (0, 0)),
-                                                    (8, 4, (210, 207))])
+                                                    (8, 4, (210, 207)), (8, 4, (311, 308))])
 def test_smt_inclusion_prove(zk_ctx, levels, populated, wbits):
     from oracle import cref
     cc = compile_circuit(circuits.smt_inclusion_circuit(levels))
@@ -299,7 +299,7 @@ def test_prove_empty_and_single(zk_ctx, poseidon_setup):
     assert np.array_equal(one[0], many[1])
 
 
-@pytest.mark.parametrize("wbits", [(7, 5), (105, 104), (0, 0), (204, 203)])
+@pytest.mark.parametrize("wbits", [(7, 5), (105, 104), (0, 0), (204, 203), (304, 303)])
 def test_degenerate_circuits(zk_ctx, wbits):
     """Smallest possible keys: one linear constraint between public inputs (no private wire at all:
     the K MSM is empty), and one product with a single internal wire (domain 2^1 / 2^0 edge)."""
@@ -351,7 +351,7 @@ def test_prove_witness_batch_matches_oracle(zk_ctx):
     assert W.shape == (batch, cc.n_wires, 4) and A.shape == (batch, cc.n_constraints, 4)
     want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp, rs)
     assert not wstatus.any()
-    for wbits in ((7, 5), (108, 106), (0, 0), (209, 208)):
+    for wbits in ((7, 5), (108, 106), (0, 0), (209, 208), (310, 309)):
         prover = groth16.Prover(zk_ctx, cc, pk, *wbits, gnark_key_layout=True)
         got = prover.prove_witness(W, A, B, Cc, rs)
         assert np.array_equal(got, want), wbits
@@ -360,6 +360,31 @@ def test_prove_witness_batch_matches_oracle(zk_ctx):
         with pytest.raises(ValueError):
             prover.prove_witness(W[:, :-1], A, B, Cc, rs)       # wrong wire count
         prover.close()
+
+
+def test_key_loaded_from_gnark_format_file(zk_ctx, tmp_path):
+    """a proving key written in gnark's raw layout (gnark_io, [UPSTREAM-RECALL],
+    parity unpinned) is read back, handed to zkmi_pk_load through gnark's own fields and proves the
+    oracle's proofs; the proofs round-trip through Proof.WriteTo bytes and verify."""
+    from gnark_crypto_primitives_amd import gnark_io, verify
+    from oracle import cref, pyref
+    cc = compile_circuit(circuits.PoseidonCircuit())
+    pk, vk, _ = groth16.setup(cc, 43, groth16.gpu_mul(zk_ctx))
+    gnark_io.save_key(str(tmp_path / "poseidon.pk"), pk, vk)
+    pk2, vk2 = gnark_io.load_key(str(tmp_path / "poseidon.pk"), cc.n_public)
+    prover = groth16.Prover(zk_ctx, cc, pk2, 8, 6, gnark_key_layout=True)
+    datas = [3, 4, 5]
+    hashes = [pyref.poseidon_hash([d]) for d in datas]
+    inp = np.stack([to_mont_array(cc.assignment_vector({"Data": d, "Hash": h}))
+                    for d, h in zip(datas, hashes)])
+    rs = np.stack([to_mont_array([7 + i, 9 + i]) for i in range(3)])
+    proofs, status = prover.prove(inp, rs)
+    prover.close()
+    want, _, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk), inp, rs)
+    assert not status.any() and np.array_equal(proofs, want)
+    back = gnark_io.proof_from_bytes(gnark_io.proof_to_bytes(proofs[1]))
+    assert np.array_equal(back, proofs[1])
+    assert verify.verify(vk2, [hashes[1]], back)
 
 
 def test_pk_plan_respects_budget_and_batch(zk_ctx):
@@ -377,7 +402,7 @@ def test_pk_plan_respects_budget_and_batch(zk_ctx):
     provers = []
     for budget in (1 << 28, 1 << 31):
         p = groth16.Prover(zk_ctx, cc, pk, 0, 0, table_budget_bytes=budget, max_batch=256,
-                           msm_chunk_factor=4, solve_block=128)
+                           msm_chunk_factor=4)
         info = zk_ctx.pk_info(p.pk_h)
         assert info["g1_table_bytes"] + info["g2_table_bytes"] <= budget, (budget, info)
         provers.append((p, info))
