@@ -844,7 +844,8 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
     if (cls < CLS_M || cls > CLS_BITS) return bad(r);
     for (uint32_t l = 0; l < S; l++) {
       const uint32_t* q = h + 4 * (1 + l);
-      const uint32_t op = q[0] & 0x1f, k = q[0] >> 8, dst = q[1], a = q[2], b = q[3];
+      const uint32_t op = q[0] & 0x1f, k = q[0] >> 9, dst = q[1], a = q[2], b = q[3];
+      if (((q[0] >> 6) & 7u) != cls) return bad(r);   // every quad carries its step's class
       if (op == OP_END) continue;
       bool ok = false, emits = false;
       switch (cls) {

@@ -74,9 +74,9 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // ---- VLIW solver: S sub-lanes of a wavefront per proof -----------------------------------------
 // The frontend packs independent operations of one class into steps (frontend/schedule.py); a
 // wavefront holds 64 / S proofs, lane l = (sub-lane l / (64 / S), proof l % (64 / S)), and every
-// sub-lane runs its own operand quad of the step.  Program rows are (1 + S) quads of 16 bytes: the
-// header (class, active, aux) is wave-uniform and comes through the scalar unit, the operand quad
-// is one 16-byte vector load per lane, issued one step ahead.
+// sub-lane runs its own operand quad of the step.  Program rows are (1 + S) quads of 16 bytes; the
+// operand quad is one 16-byte vector load per lane, issued one step ahead (the header quad is only
+// read by the two one-instruction classes).
 //
 // Memory order: a step's operands may have been stored by OTHER lanes of the same wavefront in an
 // earlier step.  The sub-lanes of a proof are work-items of ONE wavefront, so the release /
@@ -102,11 +102,12 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   const uint4* qp = prog + 1 + sl;
   uint4 q_next = n_rows ? qp[0] : make_uint4(0, 0, 0, 0);
   for (uint32_t r = 0; r < n_rows; r++) {
-    const uint4 hdr = prog[(size_t)r * (1 + S)];
     const uint4 q = q_next;
     if (r + 1 < n_rows) q_next = qp[(size_t)(r + 1) * (1 + S)];
-    const uint32_t cls = hdr.x & 0xffu;
-    const uint32_t op = q.x & 0x1fu, k = q.x >> 8;
+    // the step's class rides in every operand quad (also the idle ones): no dependent scalar load
+    // of the header on the critical path
+    const uint32_t cls = __builtin_amdgcn_readfirstlane((q.x >> 6) & 7u);
+    const uint32_t op = q.x & 0x1fu, k = q.x >> 9;
     const uint32_t d = q.y, x = q.z, y = q.w;
     switch (cls) {
       case CLS_M:
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
         // hdr.y pairs in the hdr.z rows that follow, S pairs per row: every sub-lane inverts its
         // own column of pairs with one field inversion (Montgomery's trick); dst rows double as
         // the prefix-product scratch; dst and src slots are distinct wires
+        const uint4 hdr = prog[(size_t)r * (1 + S)];
         const uint32_t nrows = hdr.z;
         const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1 + sl;
         Fr acc = f_one();

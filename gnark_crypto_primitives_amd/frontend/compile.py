@@ -78,7 +78,9 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     ops: SSA ops in a valid order; val_wire: value -> wire (its slot forever); row_of: op index ->
     constraint row it emits; chk: op index -> 1 when the solver must verify that row.
     Returns (vprogram uint32 [n_rows, 1 + S, 4], n_rows, n_steps, n_slots, S, cost); row = header
-    quad (class, active, aux, 0) + S operand quads (op | chk << 5 | row_k << 8, dst slot, a, b); a
+    quad (class, active, aux, 0) + S operand quads (op | chk << 5 | class << 6 | row_k << 9, dst
+    slot, a, b: the class rides in every quad so that the kernel needs the header only for the
+    two one-instruction classes); a
     BATCHINV step is followed by ceil(n / S) rows of (OP_PAIR, dst, src) quads.  Temporaries are
     recycled by step."""
     from . import schedule as sch
@@ -112,11 +114,11 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     free, n_slots = [], n_wires
     rows = []
 
-    def quad(i):
+    def quad(i, c):
         op, dst, a, b = ops[i]
         if op == OP_ABC:
-            return (op | chk.get(i, 0) << 5 | row_of[i] << 8, slot[dst], slot[a], slot[b])
-        w0 = op | (row_of[i] << 8 if i in row_of else 0)
+            return (op | chk.get(i, 0) << 5 | c << 6 | row_of[i] << 9, slot[dst], slot[a], slot[b])
+        w0 = op | c << 6 | (row_of[i] << 9 if i in row_of else 0)
         if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR):
             return (w0, slot[dst], slot[a], slot[b])
         if op in (OP_MULC, OP_ADDC):
@@ -149,7 +151,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
             i = idxs[0]
             npairs = ops[i][1]
             nrows = -(-npairs // S)
-            rows.append([(c, npairs, nrows, 0)] + [(0, 0, 0, 0)] * S)
+            rows.append([(c, npairs, nrows, 0)] + [(c << 6, 0, 0, 0)] * S)
             pairs = [(OP_PAIR, slot[ops[i + q][1]], slot[ops[i + q][2]], 0)
                      for q in range(1, npairs + 1)]
             for r in range(nrows):
@@ -157,8 +159,8 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
                 rows.append([(sch.CLS_BINV | 0x100, len(chunk), 0, 0)] + chunk +
                             [(0, 0, 0, 0)] * (S - len(chunk)))
         else:
-            quads = [quad(i) for i in idxs]
-            rows.append([hdr] + quads + [(0, 0, 0, 0)] * (S - len(quads)))
+            quads = [quad(i, c) for i in idxs]
+            rows.append([hdr] + quads + [(c << 6, 0, 0, 0)] * (S - len(quads)))
         # temporaries whose last reader is this step return to the pool for LATER steps
         for i in idxs:
             op, dst, a, b = ops[i]
@@ -371,7 +373,7 @@ class CompiledCircuit:
                 continue
             writes = []
             for w0, d, x, y in quads:
-                op, chk, k = w0 & 0x1f, (w0 >> 5) & 1, w0 >> 8
+                op, chk, k = w0 & 0x1f, (w0 >> 5) & 1, w0 >> 9
                 if op == OP_END:
                     continue
                 if op == OP_MUL:

@@ -65,6 +65,13 @@ SYMBOLS = [
     ("zkmi_prove_collect", _I, [_P, _P, _P]),
     ("zkmi_prove_witness_batch", _I, [_P, _P, _P, _P, _P, _P, _SZ, _SZ, _P, _P]),
     ("zkmi_last_timings", _I, [_P, C.POINTER(C.c_double)]),
+    ("zkmi_plonk_pk_load", _I, [_P, _P, C.POINTER(_P)]),
+    ("zkmi_plonk_pk_free", None, [_P, _P]),
+    ("zkmi_plonk_round1", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P]),
+    ("zkmi_plonk_round2", _I, [_P, _P, _P, _P]),
+    ("zkmi_plonk_round3", _I, [_P, _P, _P, _P]),
+    ("zkmi_plonk_round4", _I, [_P, _P, _P, _P]),
+    ("zkmi_plonk_round5", _I, [_P, _P, _P, _P]),
 ]
 
 _lib = None

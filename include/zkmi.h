@@ -155,7 +155,8 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
  * operations packed into steps of up to `lanes_per_proof` independent operations of one class;
  * the GPU runs a step with that many lanes of a wavefront per proof.
  *   program: n_rows x (1 + lanes_per_proof) x 4 words.  Row = header (class, active, aux, 0) +
- *   one operand quad per sub-lane (op | check << 5 | constraint_row << 8, dst slot, a, b). */
+ *   one operand quad per sub-lane (op | check << 5 | class << 6 | constraint_row << 9, dst slot,
+ *   a, b). */
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
   uint32_t n_slots, n_rows, n_consts;
