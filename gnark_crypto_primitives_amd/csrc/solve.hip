@@ -113,8 +113,10 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
       case CLS_M:
         if (op != OP_END) {
           const Fr va = LD(x);
-          const Fr vb = op == OP_MULC ? consts[y] : LD(y);
-          const Fr vc = fmul(va, vb);
+          const Fr vb = (op == OP_MULC || op == OP_FMAC) ? consts[y] : LD(y);
+          Fr vc = fmul(va, vb);
+          // fused multiply-add (frontend/relin.py): the addend's slot rides in the row-index bits
+          if (op == OP_FMA || op == OP_FMAC) vc = add(vc, LD(k));
           ST(d, vc);
           if (op == OP_MULABC) {
             bi_st_nt(a, k, lane, Bp, va);

@@ -103,19 +103,23 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     last = {}
     for t, (c, idxs) in enumerate(steps):
         for i in idxs:
-            op, dst, a, b = ops[i]
+            op, dst, a, b = ops[i][:4]
             if op == OP_BATCHINV:
                 for q in range(1, dst + 1):
                     last[ops[i + q][2]] = t
             else:
-                for v in sch.reads_of(op, dst, a, b):
+                for v in sch.reads_of(*ops[i]):
                     last[v] = t
     slot = dict(val_wire)
     free, n_slots = [], n_wires
     rows = []
 
     def quad(i, c):
-        op, dst, a, b = ops[i]
+        op, dst, a, b = ops[i][:4]
+        if op == sch.OP_FMA:       # d = a * b + z: the addend's slot rides in the row-index bits
+            return (op | c << 6 | slot[ops[i][4]] << 9, slot[dst], slot[a], slot[b])
+        if op == sch.OP_FMAC:      # d = a * const[b] + z
+            return (op | c << 6 | slot[ops[i][4]] << 9, slot[dst], slot[a], b)
         if op == OP_ABC:
             return (op | chk.get(i, 0) << 5 | c << 6 | row_of[i] << 9, slot[dst], slot[a], slot[b])
         w0 = op | c << 6 | (row_of[i] << 9 if i in row_of else 0)
@@ -135,7 +139,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         released = []
         # destinations first get their slots (sources are all older values)
         for i in idxs:
-            op, dst, a, b = ops[i]
+            op, dst, a, b = ops[i][:4]
             if op in (OP_ABC, OP_BATCHINV, OP_BITS):
                 continue
             if dst not in slot:
@@ -163,13 +167,15 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
             rows.append([hdr] + quads + [(c << 6, 0, 0, 0)] * (S - len(quads)))
         # temporaries whose last reader is this step return to the pool for LATER steps
         for i in idxs:
-            op, dst, a, b = ops[i]
+            op, dst, a, b = ops[i][:4]
             srcs = [ops[i + q][2] for q in range(1, dst + 1)] if op == OP_BATCHINV \
-                else sch.reads_of(op, dst, a, b)
+                else sch.reads_of(*ops[i])
             for v in set(srcs):
                 if last.get(v) == t and v not in val_wire and v in slot:
                     released.append(slot.pop(v))
         free.extend(released)
+    if n_slots >= 1 << 23:
+        raise ValueError("more than 2^23 value slots")     # FMA addends live in 23 bits
     vprogram = np.array(rows, dtype=np.uint32).reshape(len(rows), 1 + S, 4)
     return vprogram, len(rows), len(steps), n_slots, S, cost
 
@@ -183,14 +189,19 @@ class CompiledCircuit:
     value slots; slot i < n_wires *is* wire i.
     """
 
-    def __init__(self, api: API, layout, lanes_per_proof=0):
+    def __init__(self, api: API, layout, lanes_per_proof=0, relinearize=True):
         self.layout = layout                      # [(name, n|None, public?)]
         self._lanes_req = lanes_per_proof
+        self._relinearize = relinearize
         self.n_wires = api.n_wires
         self.n_public = api.n_public              # includes the ONE wire
         self.n_secret = api.n_secret
         self.n_constraints = len(api.constraints)
         self.n_inputs = api.n_public - 1 + api.n_secret
+        # wires the builder knows to be boolean (bit decompositions, IsZero / And / Xor results):
+        # the MSM table plan uses the fraction (groth16.Prover: zkmi_pk_desc.sparse_witness)
+        self.n_boolean_wires = sum(1 for key in api.booleans
+                                   if len(key) == 1 and key[0][1] == 1 and key[0][0] != 0)
         self.consts = list(api.const_list)
         self.constraints = api.constraints
         self.instr = np.array(api.instr, dtype=np.uint32).reshape(-1, 2)
@@ -331,6 +342,10 @@ class CompiledCircuit:
         """The program the GPU solver runs (csrc/solve.hip): see ``build_vprogram``."""
         self._ops = ops                       # post-DCE SSA ops: the PLONK lowering starts here
         self._val_wire = dict(api.val_wire)
+        if self._relinearize:
+            from .relin import relinearize
+            ops, _ = relinearize(ops, api.val_wire, self.consts, api.n_vals)
+        self.n_vops = len(ops)
         row_of, k = {}, 0                     # constraint row of every row-emitting op
         for i, o in enumerate(ops):
             if o[0] in (OP_ABC, OP_MULABC, OP_XORABC):
@@ -378,6 +393,10 @@ class CompiledCircuit:
                     continue
                 if op == OP_MUL:
                     writes.append((d, s[x] * s[y] % R))
+                elif op == sch.OP_FMA:
+                    writes.append((d, (s[x] * s[y] + s[k]) % R))
+                elif op == sch.OP_FMAC:
+                    writes.append((d, (s[x] * C[y] + s[k]) % R))
                 elif op == OP_MULC:
                     writes.append((d, s[x] * C[y] % R))
                 elif op == OP_MULABC:
@@ -517,7 +536,7 @@ class CompiledCircuit:
         return h.hexdigest()[:16]
 
 
-def compile_circuit(circuit, lanes_per_proof: int = 0) -> CompiledCircuit:
+def compile_circuit(circuit, lanes_per_proof: int = 0, relinearize: bool = True) -> CompiledCircuit:
     """``frontend.Compile(field, r1cs.NewBuilder, circuit)`` for BN254's scalar field.
     lanes_per_proof: sub-lanes of the GPU solver per proof (1, 2, 4, 8, 16; 0 = chosen from the
     schedule lengths)."""
@@ -536,4 +555,4 @@ def compile_circuit(circuit, lanes_per_proof: int = 0) -> CompiledCircuit:
                 setattr(circuit, name, [mk(f"{name}[{i}]") for i in range(f.n)])
             layout.append((name, f.n, want_public))
     circuit.define(api)
-    return CompiledCircuit(api, layout, lanes_per_proof)
+    return CompiledCircuit(api, layout, lanes_per_proof, relinearize)

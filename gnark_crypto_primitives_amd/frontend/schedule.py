@@ -9,7 +9,7 @@ executing its own (dst, a, b) of the step.  gnark's solver does the analogous th
 levelises the instructions and runs each level's chunks in goroutines.
 
 Classes (one opcode switch per step on the GPU; sub-lanes differ only in operands / small flags):
-  M  products         OP_MUL, OP_MULC, OP_MULABC
+  M  products         OP_MUL, OP_MULC, OP_MULABC, OP_FMAC, OP_FMA (fused multiply-add, relin.py)
   X  boolean xor      OP_XORABC, OP_XOR
   A  linear           OP_ADD, OP_SUB, OP_ADDC, OP_NEG, OP_COPY, OP_SETC
   R  rows             OP_ABC
@@ -24,8 +24,9 @@ import heapq
 from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COPY, OP_DIV, OP_INV, OP_MUL,
                   OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR, OP_XORABC)
 
+OP_FMAC, OP_FMA = 18, 19       # relin.py: (op, dst, x, const, addend) / (op, dst, x, y, addend)
 CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV = range(1, 8)
-CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_XORABC: CLS_X, OP_XOR: CLS_X,
+CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_FMA: CLS_M, OP_XORABC: CLS_X, OP_XOR: CLS_X,
             OP_ADD: CLS_A, OP_SUB: CLS_A, OP_ADDC: CLS_A, OP_NEG: CLS_A, OP_COPY: CLS_A,
             OP_SETC: CLS_A, OP_ABC: CLS_R, OP_INV: CLS_I, OP_DIV: CLS_I, OP_BITS: CLS_BITS,
             OP_BATCHINV: CLS_BINV}
@@ -33,7 +34,11 @@ CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_XORABC: CLS_X, O
 COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000}
 
 
-def reads_of(op, dst, a, b):
+def reads_of(op, dst, a, b, z=None):
+    if op == OP_FMA:
+        return (a, b, z)
+    if op == OP_FMAC:
+        return (a, z)
     if op == OP_ABC:
         return (dst, a, b)
     if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR):
@@ -53,7 +58,7 @@ def schedule(ops, n_bits_vals, S):
     units = []          # schedulable units: op index (BATCHINV swallows its PAIR rows)
     i = 0
     while i < n:
-        op, dst, a, b = ops[i]
+        op, dst, a, b = ops[i][:4]
         units.append(i)
         if op == OP_BATCHINV:
             for k in range(1, dst + 1):
@@ -69,11 +74,11 @@ def schedule(ops, n_bits_vals, S):
     succs = {u: [] for u in units}
     npred = {u: 0 for u in units}
     for u in units:
-        op, dst, a, b = ops[u]
+        op, dst, a, b = ops[u][:4]
         if op == OP_BATCHINV:
             rd = [ops[u + k][2] for k in range(1, dst + 1)]
         else:
-            rd = reads_of(op, dst, a, b)
+            rd = reads_of(*ops[u])
         seen = set()
         for v in rd:
             p = producer.get(v)

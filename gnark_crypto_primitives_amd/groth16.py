@@ -165,9 +165,10 @@ class Prover:
     def __init__(self, ctx: _lib.Context, cc: CompiledCircuit, pk: ProvingKey,
                  window_bits_g1: int = 0, window_bits_g2: int = 0, *, max_batch: int = 0,
                  table_budget_bytes: int = 0, msm_chunk_factor: int = 0,
-                 gnark_key_layout: bool = False):
+                 gnark_key_layout: bool = False, sparse_witness=None):
         """max_batch / table_budget_bytes / msm_chunk_factor: zkmi_pk_desc plan fields
-        (0 = default).  gnark_key_layout: describe the key the way
+        (0 = default).  sparse_witness: zkmi_pk_desc.sparse_witness; None = from the circuit (more
+        than half of its wires are known booleans: Keccak, bit decompositions).  gnark_key_layout: describe the key the way
         gnark's ProvingKey does (InfinityA / InfinityB byte maps + nbPublic) instead of wire-index
         arrays; the loaded key is the same."""
         self.ctx, self.cc, self.pk = ctx, cc, pk
@@ -194,7 +195,9 @@ class Prover:
                          pk.g1_z.shape[0], *ptrs, window_bits_g1, window_bits_g2,
                          inf_a.ctypes.data if inf_a is not None else None,
                          inf_b.ctypes.data if inf_b is not None else None, n_public,
-                         max_batch, table_budget_bytes, cc.v_n_slots, msm_chunk_factor)
+                         max_batch, table_budget_bytes, cc.v_n_slots, msm_chunk_factor,
+                         int(cc.n_boolean_wires * 2 > cc.n_wires) if sparse_witness is None
+                         else int(bool(sparse_witness)))
         self.pk_h = ctx.pk_load(pd)
 
     def close(self):

@@ -28,7 +28,8 @@ class PkDesc(C.Structure):
                 ("window_bits_g2", C.c_uint32),
                 ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("n_public", C.c_uint32),
                 ("max_batch", C.c_uint32), ("table_budget_bytes", C.c_uint64),
-                ("n_slots_hint", C.c_uint32), ("msm_chunk_factor", C.c_uint32)]
+                ("n_slots_hint", C.c_uint32), ("msm_chunk_factor", C.c_uint32),
+                ("sparse_witness", C.c_uint32)]
 
 
 class CsDesc(C.Structure):

@@ -138,6 +138,11 @@ typedef struct {
   /* Comb / shared-table MSMs: (window, chunk) blocks in flight as a multiple of the chip's wave
    * slots (measured best: 16 for comb, 8 for shared tables).  0 = default. */
   uint32_t msm_chunk_factor;
+  /* 1 = most wire values of this circuit are bits or small integers (e.g. Keccak, bit
+   * decompositions): the auto plan then keeps subset-sum comb tables for every MSM, whose zero
+   * digits are skipped, instead of sign-pattern tables (one more base per group for the same HBM,
+   * but no digit of a sign pattern is ever "nothing to add").  0 = dense field elements (Poseidon). */
+  uint32_t sparse_witness;
 } zkmi_pk_desc;
 /* Copies the key to the device and builds the MSM window tables; host buffers may be freed
  * afterwards.  One-off per circuit (gnark's icicle backend does the same lazily). */
