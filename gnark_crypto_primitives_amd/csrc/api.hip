@@ -19,7 +19,6 @@ int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out) {
       hipStreamSynchronize(ctx->stream);
       if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
       if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
-      if (ctx->stream4) hipStreamSynchronize(ctx->stream4);
       hipFree(s.p);
       s.p = nullptr;
       s.bytes = 0;
@@ -242,9 +241,6 @@ int zkmi_init(int device, zkmi_ctx** out) {
     }
   }
   for (auto& e : ctx->ev) hipEventCreate(&e);
-  if (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess) ctx->stream4 = nullptr;
-  for (auto& e : ctx->dig_done) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  for (auto& e : ctx->dig_free) hipEventCreateWithFlags(&e, hipEventDisableTiming);
   for (auto& e : ctx->part_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
   for (auto& e : ctx->acc_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
   ctx->plans.reserve(32);
@@ -258,14 +254,6 @@ void zkmi_destroy(zkmi_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
   hipStreamSynchronize(ctx->stream3);
-  if (ctx->stream4) {
-    hipStreamSynchronize(ctx->stream4);
-    hipStreamDestroy(ctx->stream4);
-  }
-  for (auto& e : ctx->dig_done)
-    if (e) hipEventDestroy(e);
-  for (auto& e : ctx->dig_free)
-    if (e) hipEventDestroy(e);
   for (auto& st : ctx->sets) {
     if (st.ev0) hipEventDestroy(st.ev0);
     if (st.ev1) hipEventDestroy(st.ev1);
@@ -471,7 +459,7 @@ static double prove_working_set_bytes(uint32_t log_n, size_t n_slots, size_t n_i
   const double sint = (double)n_msm_max * Bp * 32;
   const double partials = 2 * 21.0 * 254 * Bp * 256;
   const double sums = 2 * Bp * (7 * 128 + 2 * 256 + 256 + 256.0 * (4 * 128 + 256));
-  return 2 * set + n * Bp * 32 + 2 * (digits + sint) + partials + sums + 2e9 + 1e9;
+  return 2 * set + n * Bp * 32 + digits + sint + partials + sums + 2e9 + 1e9;
 }
 static double free_hbm_bytes() {
   size_t free_b = 0, total_b = 0;
@@ -1150,17 +1138,15 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   const bool d1 = pk->Z->plan.shared || pk->Z->plan.comb;
   const bool d2 = pk->B2->plan.shared || pk->B2->plan.comb;
   hipStream_t q3 = ctx->stream3;
-  // the wire values are ready once the solve is (S.ev1), the quotient once the NTTs are (evq[1]):
-  // with these events the digit pass of each MSM runs one MSM ahead on stream4
-  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, fd, d1 ? v.w1[0] : nullptr, q3, S.ev1)) ||
-      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, fd, d1 ? v.w1[1] : nullptr, q3, S.ev1)) ||
-      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, fd, d1 ? v.w1[2] : nullptr, q3, S.ev1)) ||
-      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr, q3, S.evq[1]))) {
+  if ((rc = msm_run(ctx, pk->A, slots, pk->a_wire, Bp, v.sA, fd, d1 ? v.w1[0] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->B1, slots, pk->b_wire, Bp, v.sB1, fd, d1 ? v.w1[1] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->K, slots, pk->k_wire, Bp, v.sK, fd, d1 ? v.w1[2] : nullptr, q3)) ||
+      (rc = msm_run(ctx, pk->Z, h, nullptr, Bp, v.sZ, false, d1 ? v.w1[3] : nullptr, q3))) {
     ctx->msm_ev_set = -1;
     return rc;
   }
   hipEventRecord(S.evq[2], ctx->stream);
-  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, fd, d2 ? v.w2 : nullptr, q3, S.ev1);
+  rc = msm_run(ctx, pk->B2, slots, pk->b_wire, Bp, v.sB2, fd, d2 ? v.w2 : nullptr, q3);
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);

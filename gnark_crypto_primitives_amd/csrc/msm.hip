@@ -467,6 +467,25 @@ __global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__
       }
 #pragma unroll
       for (int c = 0; c < 4; c++) {
+        // 32 x 32 bit transpose (rows = bases of the group, columns = 32 scalar bits): afterwards
+        // m[bit] holds, in bit i, bit `bit` of base i's word -- the window's index.  Five
+        // butterfly stages of 16 masked swaps instead of 32 x k single-bit extractions.
+        uint32_t m[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+          m[i] = i < KMAX ? (c == 0 ? wv[i].x : c == 1 ? wv[i].y : c == 2 ? wv[i].z : wv[i].w) : 0u;
+#pragma unroll
+        for (int jj = 16; jj != 0; jj >>= 1) {
+          const uint32_t mask = jj == 16 ? 0x0000ffffu : jj == 8 ? 0x00ff00ffu : jj == 4 ? 0x0f0f0f0fu
+                                : jj == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+          for (int kk = 0; kk < 32; kk = (kk + jj + 1) & ~jj) {
+            const uint32_t t = ((m[kk] >> jj) ^ m[kk + jj]) & mask;
+            m[kk] ^= t << jj;
+            m[kk + jj] ^= t;
+          }
+        }
+#pragma unroll
         for (int bit = 0; bit < 32; bit++) {
           int j = (h * 4 + c) * 32 + bit;
           if (SIGNED) {
@@ -475,12 +494,7 @@ __global__ __launch_bounds__(256) void comb_digits_kernel(const Fr* __restrict__
           } else if (j >= COMB_W) {
             break;
           }
-          uint32_t idx = 0;
-#pragma unroll
-          for (int i = 0; i < KMAX; i++) {
-            const uint32_t word = c == 0 ? wv[i].x : c == 1 ? wv[i].y : c == 2 ? wv[i].z : wv[i].w;
-            idx |= ((word >> bit) & 1u) << i;
-          }
+          uint32_t idx = m[bit];
           if (SIGNED) idx = ((idx >> (k - 1)) & 1u) ? (idx & low) : ((~idx & low) | 0x80000000u);
           digits[((size_t)j * n_groups + g) * Bp + b] = idx;
         }
@@ -873,7 +887,7 @@ template <> Affine<Fq2> stotal_of<Fq2>(const zkmi_msm_bases* b) { return b->stot
 template <class F>
 int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
                     const uint32_t* row_idx, size_t Bp, XYZZ<F>* out, bool scalars_f,
-                    XYZZ<F>* wsum_out, hipStream_t finish_stream, hipEvent_t scalars_ready) {
+                    XYZZ<F>* wsum_out, hipStream_t finish_stream) {
   Fr kmul = Fr::zero();
   kmul.v[0] = 1;  // plain 1: from_mont
   if (scalars_f) {  // plain 2^-5 mod r
@@ -909,20 +923,12 @@ int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
       ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[pb], 0));
       ctx->part_ev_valid[pb] = false;
     }
-    // digit pass: on the main stream, or (prover: scalars_ready given) one MSM ahead on stream4
-    // through two digit / integer-scalar buffers
-    const bool ahead = defer && scalars_ready && ctx->stream4;
-    const int db = ahead ? (int)(ctx->dig_next++ & 1u) : 0;
-    if ((rc = ensure_scratch(ctx, db ? 18 : 12, (size_t)W * G * Bp * sizeof(uint32_t), &digits)))
-      return rc;
-    if ((rc = ensure_scratch(ctx, db ? 19 : 17, n * Bp * sizeof(Fr), &sint))) return rc;
-    hipStream_t dq = ahead ? ctx->stream4 : ctx->stream;
-    if (ahead) {
-      ZK_HIP(hipStreamWaitEvent(dq, scalars_ready, 0));
-      if (ctx->dig_free_valid[db]) ZK_HIP(hipStreamWaitEvent(dq, ctx->dig_free[db], 0));
-    } else if (ctx->dig_free_valid[0]) {   // buffer 0 may still be read by a prover MSM's accumulate
-      ZK_HIP(hipStreamWaitEvent(dq, ctx->dig_free[0], 0));
-    }
+    // (Measured and dropped: the digit pass one MSM ahead on a fourth stream through two digit
+    // buffers -- correct, no gain: the pass is ALU work like the accumulate kernel it would hide
+    // under, which slowed down by exactly the pass's 7 ms.)
+    if ((rc = ensure_scratch(ctx, 12, (size_t)W * G * Bp * sizeof(uint32_t), &digits))) return rc;
+    if ((rc = ensure_scratch(ctx, 17, n * Bp * sizeof(Fr), &sint))) return rc;
+    hipStream_t dq = ctx->stream;
     XYZZ<F>* mid = (XYZZ<F>*)partial + chunks * W * Bp;
     XYZZ<F>* wsum = wsum_out ? wsum_out : mid + (size_t)ngroups * W * Bp;
     const unsigned bx = (Bp % 256 == 0) ? 256 : 64;
@@ -939,10 +945,6 @@ int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
                          (uint32_t)n, km, (const uint8_t*)bases->inf, (Fr*)sint);
       hipLaunchKernelGGL((comb_digits_kernel<20, false>), dgrid, dim3(bx), 0, dq, (const Fr*)sint,
                          Bp, (uint32_t)n, k, (uint32_t)G, (uint32_t*)digits);
-    }
-    if (ahead) {
-      ZK_HIP(hipEventRecord(ctx->dig_done[db], dq));
-      ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->dig_done[db], 0));
     }
     zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
     const int ev = (es && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
@@ -962,8 +964,6 @@ int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
       if (sg) ZK_LAUNCH_COMB(false, true); else ZK_LAUNCH_COMB(false, false);
     }
 #undef ZK_LAUNCH_COMB
-    ZK_HIP(hipEventRecord(ctx->dig_free[db], ctx->stream));
-    ctx->dig_free_valid[db] = true;
     if (ev >= 0) hipEventRecord(es->msm_ev[ev][1], ctx->stream);
     hipStream_t rq = ctx->stream;
     if (defer) {
@@ -1134,10 +1134,10 @@ template int build_comb<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPla
                              int*, Affine<Fq2>*);
 template int build_impl<Fq2>(zkmi_ctx*, const Affine<Fq2>*, size_t, const WinPlan&, Affine<Fq2>*);
 template int run_impl<Fq2>(zkmi_ctx*, const zkmi_msm_bases*, const Fr*, const uint32_t*, size_t,
-                           XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t, hipEvent_t);
+                           XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t);
 #else
 extern template int run_impl<Fq2>(zkmi_ctx*, const zkmi_msm_bases*, const Fr*, const uint32_t*,
-                                  size_t, XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t, hipEvent_t);
+                                  size_t, XYZZ<Fq2>*, bool, XYZZ<Fq2>*, hipStream_t);
 
 __global__ void fill_inf_g1(G1XYZZ* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1197,8 +1197,7 @@ int msm_horner_run(zkmi_ctx* ctx, hipStream_t stream, int count,
 }
 
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
-            size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out, hipStream_t finish_stream,
-            hipEvent_t scalars_ready) {
+            size_t Bp, void* out_xyzz, bool scalars_f, void* wsum_out, hipStream_t finish_stream) {
   if (bases->n == 0 && wsum_out && (bases->plan.shared || bases->plan.comb)) {
     // deferred path: every window sum is the identity
     const size_t cnt = (size_t)bases->plan.W * Bp;
@@ -1223,9 +1222,9 @@ int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const
   }
   if (bases->group == 1)
     return run_impl<Fq>(ctx, bases, scalars, row_idx, Bp, (G1XYZZ*)out_xyzz, scalars_f,
-                        (G1XYZZ*)wsum_out, finish_stream, scalars_ready);
+                        (G1XYZZ*)wsum_out, finish_stream);
   return run_impl<Fq2>(ctx, bases, scalars, row_idx, Bp, (G2XYZZ*)out_xyzz, scalars_f,
-                       (G2XYZZ*)wsum_out, finish_stream, scalars_ready);
+                       (G2XYZZ*)wsum_out, finish_stream);
 }
 
 int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n) {

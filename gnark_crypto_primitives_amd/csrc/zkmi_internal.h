@@ -59,14 +59,6 @@ struct zkmi_ctx {
   // `stream2` (16 wavefronts at batch 1024) underneath the NTT/MSM kernels of batch k.
   // `stream3` runs the 16-wavefront assembly of batch k underneath the quotient kernels of batch k+1.
   hipStream_t stream2 = nullptr, stream3 = nullptr;
-  // stream4: digit passes of the prover's comb MSMs (memory-bound) run here, one MSM ahead of the
-  // ALU-bound accumulate kernels on the main stream, through two digit / integer-scalar buffers;
-  // dig_done[k]: digits of buffer k written (stream4), dig_free[k]: the accumulate that read
-  // buffer k has finished (main stream)
-  hipStream_t stream4 = nullptr;
-  hipEvent_t dig_done[2] = {}, dig_free[2] = {};
-  bool dig_free_valid[2] = {false, false};
-  unsigned dig_next = 0;
   struct ProveSet {
     bool pending = false;
     bool heavy_enqueued = false;   // quotient + MSMs of this batch are already on the main stream
@@ -228,9 +220,7 @@ void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, in
 void plan_shared_for_budget(size_t n1, size_t n2, double usable_bytes, int* c1, int* c2);
 int msm_run(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars, const uint32_t* row_idx,
             size_t Bp, void* out_xyzz, bool scalars_f = false, void* wsum_out = nullptr,
-            hipStream_t finish_stream = nullptr, hipEvent_t scalars_ready = nullptr);
-// scalars_ready (comb plans, with finish_stream): the digit pass runs on ctx->stream4 once that
-// event has fired, overlapping the previous MSM's accumulate kernel.
+            hipStream_t finish_stream = nullptr);
 // With wsum_out (shared-table plans only) msm_run stops at the W window sums ([W][Bp] XYZZ) and the
 // caller finishes with msm_horner_run -- 255 dependent doublings per proof, latency-bound, which
 // the prover runs on its assembly stream under the next batch's kernels.  With finish_stream the
