@@ -135,6 +135,104 @@ template <> struct Acc29<Fq2> {
   }
 };
 
+// Accumulator of the comb kernels.  G1: registers (36 + 18 for the entry: 128 VGPRs, no spills).
+// G2 at two waves per SIMD has 256 VGPRs for a 72-limb accumulator, a 36-limb entry and ~90 limbs of
+// temporaries: the compiler spilled ~100 registers to scratch (27.9 GB of scratch writes per launch in
+// the round-2 PMC pass).  zz and zzz are only touched at the two ends of a mixed addition, so they
+// live in LDS instead (36 words x 256 lanes = 36 KB per workgroup, [limb][lane]: conflict-free) and
+// are re-read where the addition needs them the second time.
+template <class F> struct CombAcc;
+template <> struct CombAcc<Fq> {
+  static constexpr int LDS_ROWS = 1;   // unused
+  typedef G1Acc29 type;
+  static __device__ __forceinline__ type init(int32_t (*)[256], uint32_t) { return G1Acc29::infinity(); }
+  static __device__ __forceinline__ void add(type& acc, const G1Affine& e, bool negd,
+                                             int32_t (*)[256], uint32_t) {
+    madd29(acc, unpack29<Fq29Params>(e.x.v), cneg(unpack29<Fq29Params>(e.y.v), negd));
+  }
+  static __device__ __forceinline__ G1XYZZ result(const type& acc, int32_t (*)[256], uint32_t) {
+    return to_std(acc);
+  }
+};
+struct G2AccL {
+  Fq2_29 x, y;
+  bool inf;
+};
+static __device__ __forceinline__ Fq2_29 lds_ld2(int32_t (*z)[256], int row0, uint32_t t) {
+  Fq2_29 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) {
+    r.c0.v[l] = z[row0 + l][t];
+    r.c1.v[l] = z[row0 + 9 + l][t];
+  }
+  return r;
+}
+static __device__ __forceinline__ void lds_st2(int32_t (*z)[256], int row0, uint32_t t,
+                                               const Fq2_29& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) {
+    z[row0 + l][t] = a.c0.v[l];
+    z[row0 + 9 + l][t] = a.c1.v[l];
+  }
+}
+template <> struct CombAcc<Fq2> {
+  static constexpr int LDS_ROWS = 36;  // zz: rows 0..17, zzz: rows 18..35
+  typedef G2AccL type;
+  static __device__ __forceinline__ type init(int32_t (*)[256], uint32_t) {
+    G2AccL a;
+    a.x = a.y = Fq2_29::zero();
+    a.inf = true;
+    return a;
+  }
+  // ec29.h madd29(G2Acc29&, ...) with zz / zzz in LDS
+  static __device__ __forceinline__ void add(type& acc, const G2Affine& e, bool negd,
+                                             int32_t (*z)[256], uint32_t t) {
+    const Fq2_29 qx = unpack2_29(e.x), qy = cneg(unpack2_29(e.y), negd);
+    if (acc.inf) {
+      acc.x = qx;
+      acc.y = norm(qy);
+      lds_st2(z, 0, t, Fq2_29::one());
+      lds_st2(z, 18, t, Fq2_29::one());
+      acc.inf = false;
+      return;
+    }
+    const Fq2_29 u2 = mmul(qx, lds_ld2(z, 0, t));
+    const Fq2_29 s2 = mmul(qy, lds_ld2(z, 18, t));
+    const Fq2_29 p = sub(u2, acc.x);
+    const Fq2_29 r = sub(s2, acc.y);
+    const Fq2_29 pp = msqr(p);
+    const Fq2_29 rr = msqr(r);
+    if (is_zero_mulout(pp)) {
+      if (is_zero_mulout(rr)) {
+        G2Acc29 d;
+        d.inf = false;
+        mdbl29(d, qx, qy);
+        acc.x = d.x;
+        acc.y = d.y;
+        lds_st2(z, 0, t, d.zz);
+        lds_st2(z, 18, t, d.zzz);
+      } else {
+        acc.inf = true;
+      }
+      return;
+    }
+    const Fq2_29 ppp = mmul(p, pp);
+    const Fq2_29 q = mmul(acc.x, pp);
+    const Fq2_29 x3 = wred(sub(sub(rr, ppp), zk::add(q, q)));
+    const Fq2_29 y3 = wred(sub(mmul(r, sub(q, x3)), mmul(acc.y, ppp)));
+    uint32_t t2 = t;                     // opaque copy of the lane index: the second read of zz / zzz
+    asm volatile("" : "+v"(t2));         // must be a new LDS read, not the first one kept in registers
+    lds_st2(z, 0, t2, mmul(lds_ld2(z, 0, t2), pp));
+    lds_st2(z, 18, t2, mmul(lds_ld2(z, 18, t2), ppp));
+    acc.x = x3;
+    acc.y = y3;
+  }
+  static __device__ __forceinline__ G2XYZZ result(const type& acc, int32_t (*z)[256], uint32_t t) {
+    if (acc.inf) return G2XYZZ::inf();
+    return G2XYZZ{to_std(acc.x), to_std(acc.y), to_std(lds_ld2(z, 0, t)), to_std(lds_ld2(z, 18, t))};
+  }
+};
+
 // ONE_BASE only changes the symbol name: the one-base launches (delta multiples in the assembly,
 // zkmi_fixed_base_mul) then show up separately from the proving-key MSMs in rocprofv3 statistics.
 template <class F, bool ONE_BASE>
@@ -515,20 +613,22 @@ msm_accumulate_comb(const Affine<F>* __restrict__ table, const uint32_t* __restr
   uint32_t g1 = g0 + per_chunk;
   if (g1 > n_groups) g1 = n_groups;
   const uint32_t* dj = digits + (size_t)j * n_groups * Bp + b;
-  typename Acc29<F>::type acc = Acc29<F>::type::infinity();
+  __shared__ int32_t zl[CombAcc<F>::LDS_ROWS][256];
+  const uint32_t t = threadIdx.x;
+  typename CombAcc<F>::type acc = CombAcc<F>::init(zl, t);
   for (uint32_t g = g0; g < g1; g++) {
     const uint32_t m = dj[(size_t)g * Bp];
     if (SIGNED) {   // a sign pattern is never "nothing to add"
       const Affine<F> e = table[(size_t)g * per_group + (m & 0x7fffffffu)];
       if (CHECK_INF && e.is_inf()) continue;
-      Acc29<F>::add(acc, e, (m >> 31) != 0);
+      CombAcc<F>::add(acc, e, (m >> 31) != 0, zl, t);
     } else if (m) {
       const Affine<F> e = table[(size_t)g * per_group + m];
       if (CHECK_INF && e.is_inf()) continue;
-      Acc29<F>::add(acc, e, false);
+      CombAcc<F>::add(acc, e, false, zl, t);
     }
   }
-  partial[((size_t)j * gridDim.z + chunk) * Bp + b] = to_std(acc);
+  partial[((size_t)j * gridDim.z + chunk) * Bp + b] = CombAcc<F>::result(acc, zl, t);
 }
 
 // out[b] = sum_j 2^j * wsum[j][b], j < W, in two levels so that the dependent chain is short:

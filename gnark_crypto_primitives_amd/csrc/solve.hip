@@ -74,9 +74,9 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // ---- VLIW solver: S sub-lanes of a wavefront per proof -----------------------------------------
 // The frontend packs independent operations of one class into steps (frontend/schedule.py); a
 // wavefront holds 64 / S proofs, lane l = (sub-lane l / (64 / S), proof l % (64 / S)), and every
-// sub-lane runs its own operand quad of the step.  Program rows are (1 + S) quads of 16 bytes; the
-// operand quad is one 16-byte vector load per lane, issued one step ahead (the header quad is only
-// read by the two one-instruction classes).
+// sub-lane runs its own operand quad of the step.  Program rows are (1 + S) quads of 16 bytes,
+// staged through LDS in chunks of 32 rows (see the kernel); the operand quad is one ds_read_b128 per
+// lane (the header quad is only read by the two one-instruction classes).
 //
 // Memory order: a step's operands may have been stored by OTHER lanes of the same wavefront in an
 // earlier step.  The sub-lanes of a proof are work-items of ONE wavefront, so the release /
@@ -99,11 +99,44 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   int32_t st = 0;
 #define LD(i) bi_ld(slots, (i), lane, Bp)
 #define ST(i, v) bi_st(slots, (i), lane, Bp, (v))
-  const uint4* qp = prog + 1 + sl;
-  uint4 q_next = n_rows ? qp[0] : make_uint4(0, 0, 0, 0);
+  // Program rows reach the lanes through LDS, a chunk of CH rows at a time: the next chunk is
+  // loaded into registers while the current one runs and written to LDS at the chunk boundary.
+  // With the operand quad read by a vector load one step ahead, the wait for it at the top of every
+  // step was s_waitcnt vmcnt(0) -- the step counts of the switch arms differ, so the compiler cannot
+  // name the load -- which also waits for the previous step's STORES to be acknowledged before the
+  // operand loads can even be issued: one L2 round trip per step on the critical path.  LDS reads
+  // count on lgkmcnt, so the operand loads now follow the stores back to back.
+  constexpr uint32_t CH = 32, RQ = 1 + S, CQ = CH * RQ, NX = (CQ + 63) / 64;
+  __shared__ uint4 pq[CQ];
+  const uint32_t total_q = n_rows * RQ;
+  uint4 nx[NX];
+  uint32_t cur = 0xffffffffu, pre = 0xffffffffu;   // chunk in LDS / chunk in nx (wave-uniform)
   for (uint32_t r = 0; r < n_rows; r++) {
-    const uint4 q = q_next;
-    if (r + 1 < n_rows) q_next = qp[(size_t)(r + 1) * (1 + S)];
+    const uint32_t ci = r / CH;
+    if (ci != cur) {
+      if (ci != pre) {
+#pragma unroll
+        for (uint32_t i = 0; i < NX; i++) {
+          const uint32_t o = i * 64 + threadIdx.x, gq = ci * CQ + o;
+          nx[i] = (o < CQ && gq < total_q) ? prog[gq] : make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < NX; i++) {
+        const uint32_t o = i * 64 + threadIdx.x;
+        if (o < CQ) pq[o] = nx[i];
+      }
+      cur = ci;
+      pre = ci + 1;
+#pragma unroll
+      for (uint32_t i = 0; i < NX; i++) {
+        const uint32_t o = i * 64 + threadIdx.x, gq = pre * CQ + o;
+        nx[i] = (o < CQ && gq < total_q) ? prog[gq] : make_uint4(0, 0, 0, 0);
+      }
+      __syncthreads();   // one wavefront per workgroup: orders the LDS writes before the reads
+    }
+    const uint32_t rr = r - ci * CH;
+    const uint4 q = pq[(r - ci * CH) * RQ + 1 + sl];
     // the step's class rides in every operand quad (also the idle ones): no dependent scalar load
     // of the header on the critical path
     const uint32_t cls = __builtin_amdgcn_readfirstlane((q.x >> 6) & 7u);
@@ -192,7 +225,7 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
         // own column of pairs with one field inversion (Montgomery's trick); dst rows double as
         // the prefix-product scratch; dst and src slots are distinct wires
         const uint4 hdr = prog[(size_t)r * (1 + S)];
-        const uint32_t nrows = hdr.z;
+        const uint32_t nrows = __builtin_amdgcn_readfirstlane(hdr.z);
         const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1 + sl;
         Fr acc = f_one();
         for (uint32_t t = 0; t < nrows; t++) {
@@ -216,7 +249,6 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           }
         }
         r += nrows;
-        if (r + 1 < n_rows) q_next = qp[(size_t)(r + 1) * (1 + S)];
         break;
       }
       default:

@@ -33,9 +33,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in rows:
             w.writerow({k: r[k] for k in w.fieldnames})
     g1 = [float(r["Counter_Value"]) for r in rows if "Fq2" not in r["Kernel_Name"]
-          and "true>" not in r["Kernel_Name"] and "comb" in r["Kernel_Name"]][-4:]
+          and "accumulate_comb" in r["Kernel_Name"]][-4:]
     g2 = [float(r["Counter_Value"]) for r in rows if "Fq2" in r["Kernel_Name"]
-          and "comb" in r["Kernel_Name"]][-1:]
+          and "accumulate_comb" in r["Kernel_Name"]][-1:]
     per[c] = (g1, g2)
 out["msm_g1_fetch_kb_per_launch"] = per["FETCH_SIZE"][0]
 out["msm_g1_write_kb_per_launch"] = per["WRITE_SIZE"][0]
