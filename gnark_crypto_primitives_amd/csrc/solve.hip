@@ -86,6 +86,64 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // store latency: 96 -> 7x ms per batch).
 enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV };
 
+// Stores of the hot step classes.  gfx950 reads the data registers of a vector store out of order
+// with later VGPR writes, so the compiler waits for a store to complete (s_waitcnt vmcnt) before it
+// reuses the registers that held the data -- which the next step's operand loads do at once: the
+// store's L2 round trip ended up on every step's critical path.  The data is therefore staged in
+// accumulation registers, which nothing else in the kernel touches: bank BANK = a[8 BANK : 8 BANK + 7].
+// WAIT (the first store of a step) waits for the PREVIOUS step's stores, issued a whole field
+// product earlier, before the bank is overwritten.  The stores are invisible to the compiler's
+// vmcnt bookkeeping; the counter completes in issue order, so an untracked older store can only
+// make one of its waits longer, never shorter.
+template <int BANK, bool WAIT, bool NT>
+__device__ __forceinline__ void st_acc(Fr* base, size_t row, size_t b, size_t Bp, const Fr& x) {
+  uint4* p0 = reinterpret_cast<uint4*>(base) + row * 2 * Bp + b;
+  uint4* p1 = p0 + Bp;
+#define ZK_ST_ACC(A0, A1, A2, A3, A4, A5, A6, A7, LO, HI)                                         \
+  if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+  if (NT)                                                                                          \
+    asm volatile("v_accvgpr_write_b32 " A0 ", %2\n v_accvgpr_write_b32 " A1 ", %3\n"               \
+                 "v_accvgpr_write_b32 " A2 ", %4\n v_accvgpr_write_b32 " A3 ", %5\n"               \
+                 "v_accvgpr_write_b32 " A4 ", %6\n v_accvgpr_write_b32 " A5 ", %7\n"               \
+                 "v_accvgpr_write_b32 " A6 ", %8\n v_accvgpr_write_b32 " A7 ", %9\n s_nop 1\n"     \
+                 "global_store_dwordx4 %0, " LO ", off nt\n global_store_dwordx4 %1, " HI ", off nt" \
+                 :: "v"(p0), "v"(p1), "v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]),          \
+                    "v"(x.v[4]), "v"(x.v[5]), "v"(x.v[6]), "v"(x.v[7])                             \
+                 : A0, A1, A2, A3, A4, A5, A6, A7, "memory");                                      \
+  else                                                                                             \
+    asm volatile("v_accvgpr_write_b32 " A0 ", %2\n v_accvgpr_write_b32 " A1 ", %3\n"               \
+                 "v_accvgpr_write_b32 " A2 ", %4\n v_accvgpr_write_b32 " A3 ", %5\n"               \
+                 "v_accvgpr_write_b32 " A4 ", %6\n v_accvgpr_write_b32 " A5 ", %7\n"               \
+                 "v_accvgpr_write_b32 " A6 ", %8\n v_accvgpr_write_b32 " A7 ", %9\n s_nop 1\n"     \
+                 "global_store_dwordx4 %0, " LO ", off\n global_store_dwordx4 %1, " HI ", off"      \
+                 :: "v"(p0), "v"(p1), "v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]),          \
+                    "v"(x.v[4]), "v"(x.v[5]), "v"(x.v[6]), "v"(x.v[7])                             \
+                 : A0, A1, A2, A3, A4, A5, A6, A7, "memory")
+  if (BANK == 0) {
+    ZK_ST_ACC("a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a[0:3]", "a[4:7]");
+  } else if (BANK == 1) {
+    ZK_ST_ACC("a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a[8:11]", "a[12:15]");
+  } else if (BANK == 2) {
+    ZK_ST_ACC("a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a[16:19]", "a[20:23]");
+  } else {
+    ZK_ST_ACC("a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a[24:27]", "a[28:31]");
+  }
+#undef ZK_ST_ACC
+}
+
+// value-file slot i of this proof, or constant i: one pair of loads from a per-lane address
+__device__ __forceinline__ Fr ld_sel(const Fr* slots, const Fr* consts, uint32_t i, bool is_const,
+                                     size_t lane, size_t Bp) {
+  const uint4* p0 = is_const ? reinterpret_cast<const uint4*>(consts + i)
+                             : reinterpret_cast<const uint4*>(slots) + (size_t)i * 2 * Bp + lane;
+  const uint4* p1 = p0 + (is_const ? (size_t)1 : Bp);
+  const uint4 lo = *p0, hi = *p1;
+  Fr r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+
 template <int S>
 __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict__ prog,
                                                         const Fr* __restrict__ consts, Fr* slots,
@@ -99,6 +157,8 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   int32_t st = 0;
 #define LD(i) bi_ld(slots, (i), lane, Bp)
 #define ST(i, v) bi_st(slots, (i), lane, Bp, (v))
+#define STA(i, v) st_acc<0, true, false>(slots, (i), lane, Bp, (v))
+#define LDSEL(i, isc) ld_sel(slots, consts, (i), (isc), lane, Bp)
   // Program rows reach the lanes through LDS, a chunk of CH rows at a time: the next chunk is
   // loaded into registers while the current one runs and written to LDS at the chunk boundary.
   // With the operand quad read by a vector load one step ahead, the wait for it at the top of every
@@ -145,16 +205,21 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
     switch (cls) {
       case CLS_M:
         if (op != OP_END) {
+          // Operand fetches have no divergent alternatives (constant table or value file, addend
+          // or none): both sides of a divergent if would land in the same registers, and the
+          // compiler then waits with vmcnt(0) -- for the previous step's stores too -- between them.
+          const bool kc = op == OP_MULC || op == OP_FMAC, fma = op == OP_FMA || op == OP_FMAC;
           const Fr va = LD(x);
-          const Fr vb = (op == OP_MULC || op == OP_FMAC) ? consts[y] : LD(y);
-          Fr vc = fmul(va, vb);
+          const Fr vb = LDSEL(y, kc);
           // fused multiply-add (frontend/relin.py): the addend's slot rides in the row-index bits
-          if (op == OP_FMA || op == OP_FMAC) vc = add(vc, LD(k));
-          ST(d, vc);
+          const Fr vz = LD(fma ? k : x);
+          Fr vc = fmul(va, vb);
+          if (fma) vc = add(vc, vz);
+          STA(d, vc);
           if (op == OP_MULABC) {
-            bi_st_nt(a, k, lane, Bp, va);
-            bi_st_nt(b, k, lane, Bp, vb);
-            bi_st_nt(c, k, lane, Bp, vc);
+            st_acc<1, false, true>(a, k, lane, Bp, va);
+            st_acc<2, false, true>(b, k, lane, Bp, vb);
+            st_acc<3, false, true>(c, k, lane, Bp, vc);
           }
         }
         break;
@@ -163,48 +228,47 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           const Fr va = LD(x), vb = LD(y);
           const Fr ab = fmul(va, vb);
           const Fr ab2 = add(ab, ab);
-          ST(d, sub(add(va, vb), ab2));
+          STA(d, sub(add(va, vb), ab2));
           if (op == OP_XORABC) {   // OP_XOR: value only (PLONK lowering: rows come from OP_ABC)
-            bi_st_nt(a, k, lane, Bp, add(va, va));
-            bi_st_nt(b, k, lane, Bp, vb);
-            bi_st_nt(c, k, lane, Bp, ab2);
+            st_acc<1, false, true>(a, k, lane, Bp, add(va, va));
+            st_acc<2, false, true>(b, k, lane, Bp, vb);
+            st_acc<3, false, true>(c, k, lane, Bp, ab2);
           }
         }
         break;
       case CLS_A:
         if (op != OP_END) {
+          const bool kc = op == OP_SETC || op == OP_ADDC;
+          const bool two = kc || op == OP_ADD || op == OP_SUB;
+          const Fr va = LD(x);                      // OP_SETC: x = 0, the constant-one slot
+          const Fr vb = LDSEL(two ? y : x, kc);
           Fr v;
-          if (op == OP_SETC) {
-            v = consts[y];
-          } else {
-            const Fr va = LD(x);
-            if (op == OP_ADD)
-              v = add(va, LD(y));
-            else if (op == OP_SUB)
-              v = sub(va, LD(y));
-            else if (op == OP_ADDC)
-              v = add(va, consts[y]);
-            else if (op == OP_NEG)
-              v = neg(va);
-            else
-              v = va;   // OP_COPY
-          }
-          ST(d, v);
+          if (op == OP_SETC)
+            v = vb;
+          else if (op == OP_ADD || op == OP_ADDC)
+            v = add(va, vb);
+          else if (op == OP_SUB)
+            v = sub(va, vb);
+          else if (op == OP_NEG)
+            v = neg(va);
+          else
+            v = va;   // OP_COPY
+          STA(d, v);
         }
         break;
       case CLS_R:
         if (op != OP_END) {
           const Fr va = LD(d), vb = LD(x), vc = LD(y);
-          bi_st_nt(a, k, lane, Bp, va);
-          bi_st_nt(b, k, lane, Bp, vb);
-          bi_st_nt(c, k, lane, Bp, vc);
+          st_acc<1, true, true>(a, k, lane, Bp, va);
+          st_acc<2, false, true>(b, k, lane, Bp, vb);
+          st_acc<3, false, true>(c, k, lane, Bp, vc);
           if ((q.x & 0x20u) && fmul(va, vb) != vc) st = ZKMI_ERR_UNSATISFIED;
         }
         break;
       case CLS_I:
         if (op != OP_END) {
-          const Fr va = LD(x);
-          ST(d, op == OP_DIV ? fmul(va, finv(LD(y))) : finv(va));
+          const Fr va = LD(x), vy = LD(op == OP_DIV ? y : x);
+          STA(d, op == OP_DIV ? fmul(va, finv(vy)) : finv(va));
         }
         break;
       case CLS_BITS: {
@@ -218,6 +282,9 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           const uint32_t bit = i < 256 ? (v.v[i >> 5] >> (i & 31)) & 1u : 0u;
           ST(q0.y + i, bit ? one : zero);
         }
+        // compiler-visible stores: complete them here, or the register-reuse waits they force
+        // (see st_acc) would reappear at the top of every following step
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         break;
       }
       case CLS_BINV: {
@@ -249,6 +316,7 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           }
         }
         r += nrows;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as after CLS_BITS
         break;
       }
       default:
@@ -258,6 +326,8 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   }
 #undef LD
 #undef ST
+#undef STA
+#undef LDSEL
   // a proof is unsatisfied if any of its sub-lanes saw a failing row
   if (st) atomicMin(&status[lane], st);
 }
