@@ -178,6 +178,23 @@ def vk_digest(key):
 
 
 # ---- prover ----------------------------------------------------------------------------------------------
+def blinded_poly(vals, bs, log_n):
+    """coefficients of the interpolant of `vals` on the domain + (bs[0] X^(k-1) + ... + bs[-1]) (X^n - 1)"""
+    n = 1 << log_n
+    cf = ntt(list(vals) + [0] * (n - len(vals)), log_n, inverse=True) + [0] * len(bs)
+    for j, bj in enumerate(reversed(bs)):          # bj multiplies X^j
+        cf[j] = (cf[j] - bj) % R
+        cf[n + j] = (cf[n + j] + bj) % R
+    return cf
+
+
+def round1_commitments(srs_img, log_n, a, b, c, blind):
+    """[a], [b], [c] of the prover's first round alone (for circuits too large to run the whole
+    Python prover on): blinded wire polynomials committed through the C oracle's MSM."""
+    return tuple(commit(srs_img, blinded_poly(col, blind[2 * i:2 * i + 2], log_n))
+                 for i, col in enumerate((a, b, c)))
+
+
 def prove(key, a, b, c, public, blind):
     """a, b, c: gate columns (ints); public: public inputs; blind: 9 scalars.  Returns the proof
     dict {a, b, c, z, tlo, tmid, thi, wz, wzw (points); ev = (a, b, c, s1, s2, zw) at zeta}."""
@@ -187,12 +204,7 @@ def prove(key, a, b, c, public, blind):
     srs, lag, coef = key["srs"], key["lag"], key["coef"]
 
     def blinded(vals, bs):
-        cf = ntt(vals, log_n, inverse=True) + [0] * len(bs)
-        # + (bs[0] X^(k-1) + ... + bs[-1]) (X^n - 1)
-        for j, bj in enumerate(reversed(bs)):          # bj multiplies X^j
-            cf[j] = (cf[j] - bj) % R
-            cf[n + j] = (cf[n + j] + bj) % R
-        return cf
+        return blinded_poly(vals, bs, log_n)
     ca, cb, cc = blinded(a, blind[0:2]), blinded(b, blind[2:4]), blinded(c, blind[4:6])
     A, B, C = commit(srs, ca), commit(srs, cb), commit(srs, cc)
     vkd = vk_digest(key)

@@ -79,3 +79,45 @@ def test_smt_plonk_vs_oracle(zk_ctx):
     assert _same(proofs[1], _oracle_proof(P, key, sc, inps[1], blinds[1]))
     for i in range(3):
         assert plonk.verify(pk, [], proofs[i])
+
+
+def test_config5_address_on_plonk_backend(zk_ctx):
+    """BASELINE config 5 as it is worded: the secp256k1 address circuit (`ecdsa.DeriveAddress`,
+    ecc/secp256k1/ecdsa/address.go:14-40) on the PLONK backend at full size: 231 270 gates, domain
+    2^18, quotient on 2^20.  The Python prover is too slow at this size, so the oracle side is
+    (i) the first-round commitments [a], [b], [c] recomputed from a CPU execution of the witness
+    program (Python inverse NTTs, C oracle MSM), bit for bit, (ii) the oracle's verifier and the
+    product's on the complete proofs, (iii) a wrong address flagged by the solver and rejected by
+    the verifiers.  Parity unpinned with respect to gnark (address_test.go:57 proves with Groth16)."""
+    from oracle import plonk_ref as P
+    from gnark_crypto_primitives_amd import workloads
+    circuit, gen, _ = workloads.build("address")
+    sc = compile_scs(circuit)
+    assert sc.log_n == 18 and sc.n_gates > 200_000
+    pk = plonk.setup(zk_ctx, sc, 11)
+    prover = plonk.Prover(zk_ctx, sc, pk, max_batch=64)
+    rng = random.Random(55)
+    asg = [gen(rng) for _ in range(3)]
+    wrong = dict(asg[2])
+    wrong["Address"] = (wrong["Address"] + 1) % (1 << 160)
+    inps = [sc.assignment_vector(a) for a in (asg[0], asg[1], wrong)]
+    blinds = [[rng.randrange(R) for _ in range(9)] for _ in inps]
+    proofs, status = prover.prove(np.stack([to_mont_array(v) for v in inps]),
+                                  np.stack([to_mont_array(v) for v in blinds]))
+    prover.close()
+    assert list(status != 0) == [False, False, True]
+    n_pub = sc.n_public - 1
+    # (i) round 1 against the oracle
+    _, a, b, c = sc.run_vprogram(inps[1])
+    want = P.round1_commitments(pk.srs_g1, sc.log_n, a, b, c, blinds[1])
+    assert (proofs[1].a, proofs[1].b, proofs[1].c) == want
+    # (ii) complete proofs under both verifiers (the oracle's takes the verifying key as data)
+    vkey = {"log_n": pk.log_n, "n_pub": n_pub, "com": pk.com, "g2_tau": pk.g2_tau}
+    for i in (0, 1):
+        pub = inps[i][:n_pub]
+        assert plonk.verify(pk, pub, proofs[i])
+        assert P.verify(vkey, pub, {**{f: getattr(proofs[i], f) for f in plonk.Proof.FIELDS},
+                                    "ev": proofs[i].ev})
+    # (iii) the wrong address: neither its own public inputs nor the right ones make it verify
+    assert not plonk.verify(pk, inps[2][:n_pub], proofs[2])
+    assert not plonk.verify(pk, inps[1][:n_pub], proofs[0])
