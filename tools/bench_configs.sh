@@ -11,4 +11,4 @@ run verifier --workload verifier --batch 1024
 run address --workload address --batch 512 --distinct 32
 # PLONK backend (config 5 as BASELINE.json words it, and the small circuits)
 run plonk-poseidon --backend plonk --workload poseidon --batch 1024 --distinct 64
-run plonk-address --backend plonk --workload address --batch 64 --distinct 8 --steps 2
+run plonk-address --backend plonk --workload address --batch 512 --distinct 8 --steps 2
