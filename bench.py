@@ -384,7 +384,7 @@ def main():
             madds = sum(ns) * info["g1_windows"] * B
         roofline["alu"] = {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": madds * 1467 / msm_s,
                            "peak": 3.55e13, "frac": madds * 1467 / msm_s / 3.55e13}
-        if info["g1_comb_k"] and info["g1_windows"] == 254:
+        if (info["g1_comb_k"] and info["g1_windows"] == 254) or cc.n_boolean_wires * 2 > cc.n_wires:
             # subset-sum tables skip every all-zero digit (bit-valued witnesses skip most of them):
             # the additions actually executed are not counted, so this view is only an upper bound
             roofline["alu"]["frac"] = None

@@ -733,6 +733,25 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
     if (auto1 && (double)COMB_WINDOWS / k1 < (double)p1.W) p1 = plan_comb(k1, s1);
     if (auto2 && (double)COMB_WINDOWS / k2 < (double)p2.W) p2 = plan_comb(k2, s2);
   }
+  // sparse_witness = 2: (almost) every wire is a bit.  The wire MSMs then execute one addition per
+  // group (window 0) whatever the group size, so they get small subset-sum tables and the dense
+  // quotient MSM (h . Z) gets the HBM: the widest table that fits, sign patterns allowed.
+  WinPlan p1z = p1;
+  if (d->sparse_witness >= 2 && auto1 && auto2 && n1 >= 4096 && d->n_z >= 4096) {
+    const int kw = 12;
+    const double wire_bytes =
+        (double)((d->n_a + kw - 1) / kw + (d->n_b + kw - 1) / kw + (d->n_k + kw - 1) / kw) *
+            (double)(1u << kw) * 64.0 +
+        (double)((d->n_b + kw - 1) / kw) * (double)(1u << kw) * 128.0;
+    if (wire_bytes < 0.5 * usable) {
+      int kz = 0, k2 = 0;
+      bool sz = true, s2 = true;
+      plan_comb_for_budget(d->n_z, 0, 0.98 * usable - wire_bytes, &kz, &k2, &sz, &s2, true);
+      p1 = plan_comb(kw, false);
+      p2 = plan_comb(kw, false);
+      p1z = plan_comb(kz, sz);
+    }
+  }
   auto load = [&](int group, const void* pts, size_t n, const WinPlan& plan, bool relax,
                   zkmi_msm_bases** out) -> int {
     Staged sb(ctx);
@@ -748,7 +767,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       (rc = load(1, d->g1_a, d->n_a, p1, auto1, &pk->A)) ||
       (rc = load(1, d->g1_b, d->n_b, p1, auto1, &pk->B1)) ||
       (rc = load(1, d->g1_k, d->n_k, p1, auto1, &pk->K)) ||
-      (rc = load(1, d->g1_z, d->n_z, p1, auto1, &pk->Z)) ||
+      (rc = load(1, d->g1_z, d->n_z, p1z, auto1, &pk->Z)) ||
       (rc = load(2, d->g2_b, d->n_b, p2, auto2, &pk->B2))) {
     zkmi_pk_free(ctx, pk);
     return rc;

@@ -196,8 +196,9 @@ class Prover:
                          inf_a.ctypes.data if inf_a is not None else None,
                          inf_b.ctypes.data if inf_b is not None else None, n_public,
                          max_batch, table_budget_bytes, cc.v_n_slots, msm_chunk_factor,
-                         int(cc.n_boolean_wires * 2 > cc.n_wires) if sparse_witness is None
-                         else int(bool(sparse_witness)))
+                         (2 if cc.n_boolean_wires * 100 >= cc.n_wires * 99 else
+                          int(cc.n_boolean_wires * 2 > cc.n_wires)) if sparse_witness is None
+                         else int(sparse_witness))
         self.pk_h = ctx.pk_load(pd)
 
     def close(self):

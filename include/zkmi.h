@@ -141,7 +141,10 @@ typedef struct {
   /* 1 = most wire values of this circuit are bits or small integers (e.g. Keccak, bit
    * decompositions): the auto plan then keeps subset-sum comb tables for every MSM, whose zero
    * digits are skipped, instead of sign-pattern tables (one more base per group for the same HBM,
-   * but no digit of a sign pattern is ever "nothing to add").  0 = dense field elements (Poseidon). */
+   * but no digit of a sign pattern is ever "nothing to add").  2 = (almost) all wires are bits: the
+   * wire MSMs additionally get small tables (one addition per group is all they execute) and the
+   * quotient MSM, whose scalars are dense, takes the freed HBM with its own, wider plan.
+   * 0 = dense field elements (Poseidon). */
   uint32_t sparse_witness;
 } zkmi_pk_desc;
 /* Copies the key to the device and builds the MSM window tables; host buffers may be freed
