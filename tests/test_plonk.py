@@ -50,6 +50,9 @@ def test_plonk_oracle_proves_and_verifies():
     proof = P.prove(key, a, b, c, pub, blind)
     assert P.verify(key, pub, proof)
     assert P.prove(key, a, b, c, pub, blind) == proof                      # deterministic
+    # the first-round helper the full-size GPU test uses is the prover's own first round
+    assert P.round1_commitments(key["srs"], sc.log_n, a, b, c, blind) == \
+        (proof["a"], proof["b"], proof["c"])
     assert P.prove(key, a, b, c, pub, [x + 1 for x in blind]) != proof     # blinding matters
     bad = dict(proof, ev=(proof["ev"][0] + 1,) + proof["ev"][1:])
     assert not P.verify(key, pub, bad)
