@@ -14,9 +14,14 @@ out = {"source": f"profiles/{tag}_pmc_fetch_size.csv + {tag}_pmc_write_size.csv 
                  "FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh: bench.py --steps 1 "
                  "--warmup 1 --cpu-sample 0 --no-pipeline --worst-case-steps 0); last four launches "
                  "of the G1 comb kernel = the timed step (A, B1, K, Z)",
-       "note": "raw counter values x 1024 (counters are in KB).  FETCH_SIZE is NOT corrected: "
-               "MI355X_MICROARCH.md calibrates its 2x under-count only for wide coalesced streams; "
-               "these are 64-byte table gathers, and the Z launch's count equals its gathered bytes",
+       "note": "counter values x 1024 (the counters are in KB).  MI355X_MICROARCH.md (HBM section): "
+               "FETCH_SIZE under-counts wide coalesced streams by 2x and is uncalibrated for other "
+               "access widths -> calibrate on a known byte count in the kernel's own pattern.  This "
+               "kernel's pattern is one 64-byte table entry per lane; the Z launch is the "
+               "calibration: 3450 groups x 255 windows x 1024 proofs x 64 B = 57.6 GB gathered, "
+               "FETCH_SIZE reports 56.3-57.7 GB (a few entries repeat within a wave) -> factor 1.0 "
+               "for these gathers, no doubling applied.  WRITE_SIZE is exact for 16-byte-per-lane "
+               "stores (the partial sums)",
        "batch": bench["config"]["batch_per_gpu"], "levels": 160, "populated": 10,
        "g1_windows": bench["config"]["msm_window_tables"]["g1_windows"],
        "g1_comb_k": bench["config"]["msm_window_tables"]["g1_comb_k"]}
