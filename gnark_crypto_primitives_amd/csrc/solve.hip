@@ -30,6 +30,7 @@
 #include "zkmi_internal.h"
 #include "ff29.h"
 #include "ff29_asm.h"
+#include "modinv30.h"
 
 namespace zk {
 
@@ -48,20 +49,19 @@ __device__ __forceinline__ Fr f_one() {
   for (int i = 0; i < 8; i++) r.v[i] = Fr29Params::k261(i);
   return r;
 }
-__device__ Fr finv(const Fr& a) {  // a^(r-2): 0 -> 0 (gnark-crypto Element.Inverse convention)
-  const Fr29 A = unpack29<Fr29Params>(a.v);
-  Fr29 R = Fr29::one();
-  for (int i = 7; i >= 0; i--) {
-    uint32_t e = FrParams::p(i);
-    if (i == 0) e -= 2;
-    for (int b = 31; b >= 0; b--) {
-      R = sqr_asm(R);
-      if ((e >> b) & 1) R = mul_asm(R, A);
-    }
-  }
-  Fr r;
-  pack_canonical<Fr29Params>(r.v, R);
-  return r;
+// 1 / a in the F domain: a = x 2^261 as a canonical integer, a^-1 = x^-1 2^-261 by the fixed-count
+// divsteps of modinv30.h, times 2^783 through the F-domain product (. 2^-261) = x^-1 2^261.
+// 0 -> 0 (gnark-crypto Element.Inverse convention).  ~13 000 instructions; the Fermat power it
+// replaces (254 squarings + 130 products on the asm chains) was ~75 000: the twisted-Edwards
+// gadgets are chains of hundreds of dependent inversions (elgamal-encrypt: 715).
+__device__ Fr finv(const Fr& a) {
+  Fr t, c;
+  modinv30<ModInvFr>(t.v, a.v);
+  constexpr uint32_t c783[8] = {0x601fddb2u, 0xbafa616cu, 0x23e89803u, 0x29b4a83eu,
+                                0x44d1496bu, 0x917ad601u, 0xfe59ed6du, 0x1baa96fcu};   // 2^783 mod r
+#pragma unroll
+  for (int i = 0; i < 8; i++) c.v[i] = c783[i];
+  return fmul(t, c);
 }
 __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a plain integer
   Fr29 o = Fr29::zero();
