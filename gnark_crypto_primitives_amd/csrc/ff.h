@@ -12,6 +12,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "modinv30.h"
+
 #if defined(__HIPCC__)
 #define ZK_HD __host__ __device__ __forceinline__
 #else
@@ -221,20 +223,34 @@ ZK_HD Fp<P> from_mont(const Fp<P>& a) {
   return mul(a, o);
 }
 
-// a^(p-2): field inverse by Fermat, inverse(0) = 0 (gnark-crypto's Element.Inverse convention).
+// Field inverse, inverse(0) = 0 (gnark-crypto's Element.Inverse convention): the fixed-count
+// divsteps of modinv30.h on the canonical integer a = x 2^256, a^-1 = x^-1 2^-256, brought back into
+// the Montgomery image by one product with 2^768 (. 2^-256).  ~13 000 instructions instead of the
+// ~210 000 of a^(p-2) on this representation; same canonical result.
+template <class P> struct ModInvOf;
+template <> struct ModInvOf<FrParams> {
+  typedef ModInvFr type;
+  static ZK_HD uint32_t k768(int i) {   // 2^768 mod r
+    constexpr uint32_t v[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu,
+                               0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
+    return v[i];
+  }
+};
+template <> struct ModInvOf<FqParams> {
+  typedef ModInvFq type;
+  static ZK_HD uint32_t k768(int i) {   // 2^768 mod p
+    constexpr uint32_t v[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u,
+                               0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
+    return v[i];
+  }
+};
 template <class P>
 ZK_HD Fp<P> inverse(const Fp<P>& a) {
-  Fp<P> r = Fp<P>::one();
-  // exponent p-2, scanned MSB first; p-2 differs from p only in limb 0
-  for (int i = 7; i >= 0; i--) {
-    uint32_t e = P::p(i);
-    if (i == 0) e -= 2;
-    for (int b = 31; b >= 0; b--) {
-      r = sqr(r);
-      if ((e >> b) & 1) r = mul(r, a);
-    }
-  }
-  return r;
+  Fp<P> t, k;
+  modinv30<typename ModInvOf<P>::type>(t.v, a.v);
+#pragma unroll
+  for (int i = 0; i < 8; i++) k.v[i] = ModInvOf<P>::k768(i);
+  return mul(t, k);
 }
 
 typedef Fp<FrParams> Fr;

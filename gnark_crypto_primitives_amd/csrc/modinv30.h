@@ -13,7 +13,13 @@
 //
 // x = 0 -> 0 (gnark-crypto's Element.Inverse convention, fr/element.go [UPSTREAM-RECALL]).
 #pragma once
-#include "ff.h"
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZK_HD __host__ __device__ __forceinline__
+#else
+#define ZK_HD inline
+#endif
 
 namespace zk {
 
