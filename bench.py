@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--backend", choices=("groth16", "plonk"), default="groth16",
                     help="plonk: BASELINE config 5's backend (secondary number; one GPU, blocking "
                          "rounds with the Fiat-Shamir hashing on the host between them)")
+    ap.add_argument("--solver-lanes", type=int, default=0,
+                    help="sub-lanes of the witness solver per proof (zkmi_cs_desc.lanes_per_proof); "
+                         "0 = the frontend's choice (shortest schedule)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     if args.backend == "plonk":
@@ -181,7 +184,7 @@ def main():
         else (lambda *a: None)
     t0 = time.time()
     circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
-    cc = compile_circuit(circuit)
+    cc = compile_circuit(circuit, args.solver_lanes)
     log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops in "
         f"{cc.v_n_steps} steps x {cc.lanes_per_proof} lanes "
         f"({time.time() - t0:.1f}s)")
