@@ -156,11 +156,13 @@ def test_pipelined_submit_collect_matches_blocking(zk_ctx, poseidon_setup):
     prover.collect()
 
 
-def _prove_and_check(zk_ctx, cc, assignments, seed, wbits=(7, 5)):
+def _prove_and_check(zk_ctx, cc, assignments, seed, wbits=(7, 5), info_out=None, **plan):
     """prove a batch on the GPU and compare every proof with the C oracle."""
     from oracle import cref
     pk, vk, td = groth16.setup(cc, seed, groth16.gpu_mul(zk_ctx))
-    prover = groth16.Prover(zk_ctx, cc, pk, *wbits)
+    prover = groth16.Prover(zk_ctx, cc, pk, *wbits, **plan)
+    if info_out is not None:
+        info_out.update(zk_ctx.pk_info(prover.pk_h))
     rng = random.Random(seed)
     inp = np.stack([to_mont_array(cc.assignment_vector(a)) for a in assignments])
     rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in assignments])
@@ -280,6 +282,14 @@ def test_config5_secp256k1_address(zk_ctx):
     asg[3] = dict(asg[3], Address=asg[2]["Address"])      # someone else's address -> unsatisfied
     status = _prove_and_check(zk_ctx, cc, asg, 5, wbits=(5, 4))
     assert list(status != 0) == [False, False, False, True]
+    # the auto plan of a witness of bits (zkmi_pk_desc.sparse_witness = 2, what bench.py runs): small
+    # subset-sum tables for the wire MSMs, the dense quotient MSM on its own sign-pattern tables
+    assert cc.n_boolean_wires * 100 >= cc.n_wires * 99
+    info = {}
+    status = _prove_and_check(zk_ctx, cc, asg, 6, wbits=(0, 0), info_out=info, max_batch=64)
+    assert list(status != 0) == [False, False, False, True]
+    assert info["g2_comb_k"] == 12 and info["g2_windows"] == 254, info      # wires: subset sums
+    assert info["g1_comb_k"] >= 16 and info["g1_windows"] == 255, info      # quotient: sign patterns
 
 
 def test_prove_empty_and_single(zk_ctx, poseidon_setup):
