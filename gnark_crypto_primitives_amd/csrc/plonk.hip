@@ -24,6 +24,8 @@ struct zkmi_plonk_pk {
   Fr *coef = nullptr, *coset = nullptr, *sigma = nullptr, *omega = nullptr, *coset_x = nullptr,
      *l1 = nullptr, *zh_inv = nullptr;
   zkmi_msm_bases* srs = nullptr;
+  zkmi_msm_bases* lag[3] = {nullptr, nullptr, nullptr};   // Lagrange points of a, b, c (optional)
+  uint32_t* lag_rows[3] = {nullptr, nullptr, nullptr};    // their scalar rows (device)
   uint32_t* chunk_idx = nullptr;   // 3 x (n + 6): scalar rows of t_lo / t_mid / t_hi in the 4n buffer
   // state of the batch in flight
   size_t batch = 0, Bp = 0;
@@ -312,6 +314,10 @@ void zkmi_plonk_pk_free(zkmi_ctx* ctx, zkmi_plonk_pk* pk) {
     if (p) hipFree(p);
   if (pk->chunk_idx) hipFree(pk->chunk_idx);
   zkmi_msm_bases_free(ctx, pk->srs);
+  for (int c = 0; c < 3; c++) {
+    zkmi_msm_bases_free(ctx, pk->lag[c]);
+    if (pk->lag_rows[c]) hipFree(pk->lag_rows[c]);
+  }
   for (auto& b : pk->cf)
     if (b.p) hipFree(b.p);
   for (auto& b : pk->big)
@@ -366,6 +372,41 @@ int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* d, zkmi_plonk_pk
   if (rc) {
     zkmi_plonk_pk_free(ctx, pk);
     return rc;
+  }
+  if (d->lag_k) {   // after the SRS tables: these are small (2^k / k entries per point)
+    if (d->lag_k < 4 || d->lag_k > 16) {
+      ctx->err = "plonk pk: lag_k must be 0 or in [4,16]";
+      zkmi_plonk_pk_free(ctx, pk);
+      return ZKMI_ERR_ARG;
+    }
+    for (int c = 0; c < 3; c++) {
+      if (!d->lag_g1[c] || !d->lag_rows[c]) {
+        ctx->err = "plonk pk: lag_k set without lag_g1 / lag_rows";
+        zkmi_plonk_pk_free(ctx, pk);
+        return ZKMI_ERR_ARG;
+      }
+      std::vector<uint32_t> rows(n + 2);
+      if (hipMemcpy(rows.data(), d->lag_rows[c], (n + 2) * 4, hipMemcpyDefault) != hipSuccess) {
+        zkmi_plonk_pk_free(ctx, pk);
+        return ZKMI_ERR_HIP;
+      }
+      for (uint32_t r : rows)
+        if (r >= n + 2) {
+          ctx->err = "plonk pk: lag_rows entry out of range";
+          zkmi_plonk_pk_free(ctx, pk);
+          return ZKMI_ERR_ARG;
+        }
+      if (hipMalloc((void**)&pk->lag_rows[c], (n + 2) * 4) != hipSuccess ||
+          hipMemcpy(pk->lag_rows[c], rows.data(), (n + 2) * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        zkmi_plonk_pk_free(ctx, pk);
+        return ZKMI_ERR_HIP;
+      }
+      // 200 + k: subset-sum comb tables over groups of k points (zero digits are skipped)
+      if ((rc = zkmi_msm_bases_load(ctx, 1, d->lag_g1[c], n + 2, 200 + (int)d->lag_k, &pk->lag[c]))) {
+        zkmi_plonk_pk_free(ctx, pk);
+        return rc;
+      }
+    }
   }
   *out = pk;
   return ZKMI_OK;
@@ -451,8 +492,23 @@ int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const
                        2 * k, 2, Bp);
   }
   ZK_HIP(hipGetLastError());
-  const Fr* sc[3] = {(Fr*)pk->cf[0].p, (Fr*)pk->cf[1].p, (Fr*)pk->cf[2].p};
-  if ((rc = commit(ctx, pk, 3, sc, nullptr, commits_out, batch))) return rc;
+  if (pk->lag[0]) {
+    // Lagrange basis: the columns' values are the scalars; rows n, n + 1 of a column buffer take
+    // its blinding scalars b1, b2 (points [tau^(n+1) - tau], [tau^n - 1])
+    if ((rc = buf(ctx, pk->small[2], Bp * 128)) || (rc = buf(ctx, pk->small[3], Bp * 64))) return rc;
+    for (int k = 0; k < 3; k++) {
+      ZK_HIP(hipMemcpyAsync(cols[k] + n * Bp, (const Fr*)pk->small[0].p + (size_t)(2 * k) * Bp,
+                            2 * Bp * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+      if ((rc = msm_run(ctx, pk->lag[k], cols[k], pk->lag_rows[k], Bp, pk->small[2].p))) return rc;
+      if ((rc = xyzz_to_affine(ctx, 1, pk->small[2].p, pk->small[3].p, Bp))) return rc;
+      ZK_HIP(hipMemcpy2DAsync((char*)commits_out + (size_t)k * 64, (size_t)3 * 64, pk->small[3].p, 64,
+                              64, batch, hipMemcpyDefault, ctx->stream));
+    }
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    const Fr* sc[3] = {(Fr*)pk->cf[0].p, (Fr*)pk->cf[1].p, (Fr*)pk->cf[2].p};
+    if ((rc = commit(ctx, pk, 3, sc, nullptr, commits_out, batch))) return rc;
+  }
   pk->round = 1;
   return ZKMI_OK;
 }

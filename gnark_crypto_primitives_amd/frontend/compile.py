@@ -200,8 +200,9 @@ class CompiledCircuit:
         self.n_inputs = api.n_public - 1 + api.n_secret
         # wires the builder knows to be boolean (bit decompositions, IsZero / And / Xor results):
         # the MSM table plan uses the fraction (groth16.Prover: zkmi_pk_desc.sparse_witness)
-        self.n_boolean_wires = sum(1 for key in api.booleans
-                                   if len(key) == 1 and key[0][1] == 1 and key[0][0] != 0)
+        self.boolean_wires = {key[0][0] for key in api.booleans
+                              if len(key) == 1 and key[0][1] == 1 and key[0][0] != 0}
+        self.n_boolean_wires = len(self.boolean_wires)
         self.consts = list(api.const_list)
         self.constraints = api.constraints
         self.instr = np.array(api.instr, dtype=np.uint32).reshape(-1, 2)

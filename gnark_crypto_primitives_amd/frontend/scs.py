@@ -144,6 +144,35 @@ class ScsCircuit:
                 sigma[p] = pos[(i + 1) % len(pos)]
         self.sigma = sigma
         self.wires = wires
+        # Rows of each column whose value is known to be a bit (a wire the builder knows boolean,
+        # the ONE wire, padding rows): the Lagrange-basis commitment of a column (plonk.py) orders
+        # its bases with the other rows first, so that whole groups of its subset-sum tables see
+        # one-bit scalars.  Only speed depends on this classification, never a result.
+        val_wire = self.cc._val_wire
+        bw = self.cc.boolean_wires
+        bitv = {0} | {v for v, w in val_wire.items() if w in bw}
+        C = self.consts
+        for op, d, a, b in self.cc._ops:          # bits stay bits under and / xor / not / copy
+            if op in (OP_MUL, OP_MULABC, OP_XOR, OP_XORABC):
+                if a in bitv and b in bitv:
+                    bitv.add(d)
+            elif op == OP_SUB:
+                if a == 0 and b in bitv:          # 1 - b
+                    bitv.add(d)
+            elif op == OP_COPY:
+                if a in bitv:
+                    bitv.add(d)
+            elif op == OP_SETC:
+                if C[b] in (0, 1):
+                    bitv.add(d)
+        is_bit = lambda v: v in bitv
+        self.lag_order = []
+        for c in range(3):
+            head = [r for r, v in enumerate(wires[c]) if not is_bit(v)]
+            hs = set(head)
+            self.lag_order.append(np.array(head + [r for r in range(n) if r not in hs],
+                                           dtype=np.uint32))
+            self.n_nonbit_rows = max(getattr(self, "n_nonbit_rows", 0), len(head))
 
     def is_satisfied(self, a, b, c, public):
         """gate equations + copy constraints on full columns (lists of ints, length n_gates)."""

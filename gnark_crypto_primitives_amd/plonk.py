@@ -68,7 +68,8 @@ class PlonkDesc(C.Structure):
     _fields_ = [("log_n", C.c_uint32), ("n_public", C.c_uint32), ("coef", C.c_void_p),
                 ("coset", C.c_void_p), ("sigma", C.c_void_p), ("omega", C.c_void_p),
                 ("coset_x", C.c_void_p), ("l1_coset", C.c_void_p), ("zh_inv", C.c_void_p),
-                ("srs_g1", C.c_void_p), ("window_bits", C.c_uint32), ("max_batch", C.c_uint32)]
+                ("srs_g1", C.c_void_p), ("window_bits", C.c_uint32), ("max_batch", C.c_uint32),
+                ("lag_g1", C.c_void_p * 3), ("lag_rows", C.c_void_p * 3), ("lag_k", C.c_uint32)]
 
 
 class ProvingKey:
@@ -79,6 +80,7 @@ class ProvingKey:
         self.n_public = 0
         self.coef = self.coset = self.sigma = self.omega = self.coset_x = self.l1 = None
         self.zh_inv = self.srs_g1 = None
+        self.srs_lagrange = None   # n + 2 points: [L_i(tau)]_1, [tau^(n+1) - tau]_1, [tau^n - 1]_1
         self.com = {}              # name -> G1 point (ints) of qL..qC, S1..S3
         self.g2_tau = None
         self.vk_digest = b""
@@ -107,6 +109,23 @@ def setup(ctx: _lib.Context, scs: ScsCircuit, seed: int) -> ProvingKey:
     for _ in range(n):
         om.append(x)
         x = x * w % R
+    # Lagrange-form SRS (gnark's plonk.Setup takes one beside the canonical SRS [UPSTREAM-RECALL]):
+    # L_i(tau) = w^i (tau^n - 1) / (n (tau - w^i)), one batched inversion; the two points that carry
+    # the blinding (b1 X + b2)(X^n - 1) of a wire polynomial committed in this basis follow
+    den = [(tau - v) % R for v in om]
+    pref, acc = [], 1
+    for dv in den:
+        pref.append(acc)
+        acc = acc * dv % R
+    inv = _inv(acc)
+    zn = (pow(tau, n, R) - 1) * _inv(n) % R
+    lag = [0] * n
+    for i in range(n - 1, -1, -1):
+        lag[i] = om[i] * zn % R * (inv * pref[i] % R) % R
+        inv = inv * den[i] % R
+    lag += [(pow(tau, n + 1, R) - tau) % R, (pow(tau, n, R) - 1) % R]
+    pk.srs_lagrange = np.zeros((n + 2, 8), dtype=np.uint64)
+    ctx.fixed_base_mul(1, g1_gen_mont(), to_mont_array(lag), n + 2, pk.srs_lagrange)
     ident = [k * v % R for k in K for v in om]
     sig = [[ident[int(scs.sigma[c * n + r])] for r in range(n)] for c in range(3)]
     lag = [scs.qL, scs.qR, scs.qO, scs.qM, scs.qC] + sig
@@ -231,8 +250,15 @@ class Prover:
     """Device-resident (constraint system, PLONK key); ``prove`` runs the five GPU rounds."""
 
     def __init__(self, ctx: _lib.Context, scs: ScsCircuit, pk: ProvingKey, window_bits: int = 0,
-                 max_batch: int = 64):
+                 max_batch: int = 64, lagrange=None):
+        """lagrange: commit the wire columns a, b, c in the Lagrange basis (zkmi_plonk_pk_desc.lag_*)
+        instead of their coefficient forms.  None = when at most 40 % of the rows of a column hold
+        values the frontend cannot bound to one bit (Keccak, bit decompositions): the columns'
+        values are the scalars then, and all-zero digits cost nothing in the subset-sum tables."""
         self.ctx, self.scs, self.pk = ctx, scs, pk
+        if lagrange is None:
+            lagrange = scs.n_nonbit_rows * 5 <= 2 * (1 << scs.log_n) and scs.log_n >= 10
+        self.lagrange = bool(lagrange) and pk.srs_lagrange is not None
         self._consts = to_mont_array(scs.consts) if scs.consts else np.zeros((0, 4), np.uint64)
         prog = self._prog = np.ascontiguousarray(scs.vprogram, dtype=np.uint32)
         cd = _lib.CsDesc(scs.n_wires, scs.n_public, scs.n_secret, scs.n_constraints, scs.v_n_slots,
@@ -241,8 +267,21 @@ class Prover:
         self.cs_h = ctx.cs_load(cd)
         self._keep = [np.ascontiguousarray(x) for x in (pk.coef, pk.coset, pk.sigma, pk.omega,
                                                         pk.coset_x, pk.l1, pk.zh_inv, pk.srs_g1)]
-        d = PlonkDesc(pk.log_n, pk.n_public, *[x.ctypes.data for x in self._keep], window_bits,
-                      max_batch)
+        lag_g1 = (C.c_void_p * 3)()
+        lag_rows = (C.c_void_p * 3)()
+        lag_k = 0
+        if self.lagrange:
+            n = 1 << pk.log_n
+            lag_k = 10
+            for c in range(3):
+                # blinding points first (their scalars are field elements), then the column's rows
+                order = np.concatenate([np.array([n, n + 1], dtype=np.uint32), scs.lag_order[c]])
+                pts = np.ascontiguousarray(pk.srs_lagrange[order])
+                self._keep += [order, pts]
+                lag_g1[c] = pts.ctypes.data
+                lag_rows[c] = order.ctypes.data
+        d = PlonkDesc(pk.log_n, pk.n_public, *[x.ctypes.data for x in self._keep[:8]], window_bits,
+                      max_batch, lag_g1, lag_rows, lag_k)
         h = C.c_void_p()
         ctx._check(ctx.lib.zkmi_plonk_pk_load(ctx.h, C.byref(d), C.byref(h)), "zkmi_plonk_pk_load")
         self.pk_h = h

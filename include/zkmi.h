@@ -240,6 +240,18 @@ typedef struct {
   const void* srs_g1;      /* n + 6 G1 affine points: [tau^i]_1 */
   uint32_t window_bits;    /* MSM table plan of the SRS, as zkmi_msm_bases_load */
   uint32_t max_batch;      /* 0 = 64 */
+  /* Optional (lag_k = 0: unused): commit the wire columns a, b, c in the Lagrange basis, as gnark
+   * does with its Lagrange-form SRS [UPSTREAM-RECALL], instead of their coefficient forms.  The
+   * scalars are then the witness values themselves: for circuits whose wires are mostly bits or
+   * small integers (Keccak, bit decompositions) almost every digit of the subset-sum tables is
+   * zero and skipped.  lag_g1[c] (c = 0, 1, 2 for a, b, c): n + 2 G1 points in the order the MSM
+   * groups them (lag_k per group); lag_rows[c][j] = row of column c whose value multiplies point j:
+   * a gate row r < n for [L_r(tau)]_1, n / n + 1 for the blinding points [tau^(n+1) - tau]_1 /
+   * [tau^n - 1]_1 (scalars b1 / b2 of the column).  Order rows of large values first; only speed
+   * depends on the order.  Same commitments as in coefficient form. */
+  const void* lag_g1[3];
+  const uint32_t* lag_rows[3];
+  uint32_t lag_k;          /* bases per subset-sum table of the Lagrange points, 4 .. 16; 0 = off */
 } zkmi_plonk_pk_desc;
 int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* desc, zkmi_plonk_pk** out);
 void zkmi_plonk_pk_free(zkmi_ctx* ctx, zkmi_plonk_pk* pk);

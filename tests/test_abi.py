@@ -29,8 +29,10 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof of the descriptor structs as a C compiler lays out include/zkmi.h, against
     the ctypes mirrors in lib.py (what a cgo caller would see too)."""
     import subprocess
+    from gnark_crypto_primitives_amd import plonk
     fields = {"zkmi_pk_desc": [n for n, _ in lib.PkDesc._fields_],
-              "zkmi_cs_desc": [n for n, _ in lib.CsDesc._fields_]}
+              "zkmi_cs_desc": [n for n, _ in lib.CsDesc._fields_],
+              "zkmi_plonk_pk_desc": [n for n, _ in plonk.PlonkDesc._fields_]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "zkmi.h"', 'int main(void) {']
     for st, fs in fields.items():
         prog.append(f'printf("{st} %zu\\n", sizeof({st}));')
@@ -42,7 +44,8 @@ def test_struct_layouts_match_header(tmp_path):
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
-    for st, cls in (("zkmi_pk_desc", lib.PkDesc), ("zkmi_cs_desc", lib.CsDesc)):
+    for st, cls in (("zkmi_pk_desc", lib.PkDesc), ("zkmi_cs_desc", lib.CsDesc),
+                    ("zkmi_plonk_pk_desc", plonk.PlonkDesc)):
         assert int(out[st]) == C.sizeof(cls), st
         for f in fields[st]:
             assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)

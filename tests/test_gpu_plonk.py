@@ -60,6 +60,34 @@ def test_poseidon_plonk_vs_oracle(zk_ctx, wbits):
     assert not plonk.verify(pk, inps[3][:1], proofs[3])                   # the unsatisfied witness
 
 
+def test_plonk_lagrange_basis_commitments(zk_ctx):
+    """Wire columns committed in the Lagrange basis (zkmi_plonk_pk_desc.lag_*: the witness values
+    are the scalars, blinding through the two extra points) give the commitments of the
+    coefficient-form path and of the oracle, bit for bit; forced on here, the address circuit's
+    full-size test below runs it by default."""
+    from oracle import plonk_ref as P
+    sc = compile_scs(circuits.smt_inclusion_circuit(4))
+    pk = plonk.setup(zk_ctx, sc, 13)
+    key = P.setup(sc, 13)
+    rng = random.Random(21)
+    inps = [sc.assignment_vector(smt_witness.synthetic_inclusion(rng, 4, k % 4)) for k in range(70)]
+    blinds = [[rng.randrange(R) for _ in range(9)] for _ in inps]
+    blinds[2] = [0] * 9
+    args = (np.stack([to_mont_array(v) for v in inps]), np.stack([to_mont_array(v) for v in blinds]))
+    out = {}
+    for mode in (True, False):
+        prover = plonk.Prover(zk_ctx, sc, pk, max_batch=128, lagrange=mode)
+        assert prover.lagrange == mode
+        out[mode] = prover.prove(*args)
+        prover.close()
+    assert not out[True][1].any() and not out[False][1].any()
+    for i in range(70):
+        assert out[True][0][i] == out[False][0][i], i
+    for i in (0, 2, 63, 64, 69):
+        assert _same(out[True][0][i], _oracle_proof(P, key, sc, inps[i], blinds[i])), i
+        assert plonk.verify(pk, [], out[True][0][i])
+
+
 def test_smt_plonk_vs_oracle(zk_ctx):
     """SMT inclusion verifier, 8 levels: 10 264 gates, domain 2^14 (quotient on 2^16)."""
     from oracle import plonk_ref as P
