@@ -42,7 +42,7 @@ def test_ntt(zk_ctx, cref, log_n, inverse, coset):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("log_n", [3, 4, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("log_n", [3, 4, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_h(zk_ctx, cref, log_n):
     r = H.rng(200 + log_n)
     n = 1 << log_n
