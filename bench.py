@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--backend", choices=("groth16", "plonk"), default="groth16",
                     help="plonk: BASELINE config 5's backend (secondary number; one GPU, blocking "
                          "rounds with the Fiat-Shamir hashing on the host between them)")
+    ap.add_argument("--msm-chunk-factor", type=int, default=0,
+                    help="zkmi_pk_desc.msm_chunk_factor (0 = the library's default, 16 for comb tables)")
     ap.add_argument("--solver-lanes", type=int, default=0,
                     help="sub-lanes of the witness solver per proof (zkmi_cs_desc.lanes_per_proof); "
                          "0 = the frontend's choice (shortest schedule)")
@@ -251,7 +253,8 @@ def main():
     pk, vk, _ = groth16.setup(cc, 2, groth16.gpu_mul(ctx))
     log(f"setup: log_n={pk.log_n} A={len(pk.a_wire)} B={len(pk.b_wire)} K={len(pk.k_wire)} "
         f"Z={pk.g1_z.shape[0]} ({time.time() - t0:.1f}s)")
-    prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2, max_batch=max(B, 64))
+    prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2, max_batch=max(B, 64),
+                            msm_chunk_factor=args.msm_chunk_factor)
     log(f"key resident, window tables built ({time.time() - t0:.1f}s)")
 
     def to_dev(a):
