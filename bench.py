@@ -3,7 +3,10 @@
 (Poseidon-BN254), batch 1024 per GPU, plus the MSM kernel's achieved algorithmic GB/s.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 either way: `python bench.py --gpus N` starts N fresh rank processes by itself (one per GPU,
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line forwarded), and under
+  `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of the
+  ranks.  --gpus that disagrees with an inherited WORLD_SIZE is an error.
 
 One step = one pass of the whole prove path (witness solve -> quotient (6 NTTs) -> 4 G1 + 1 G2 MSM ->
 assembly) over one batch of synthetic witnesses that is already resident in HBM, ending with the
@@ -44,6 +47,91 @@ def available_cpus():
     return min(n, 16)
 
 
+def host_cpus():
+    """Like available_cpus() without the per-GPU ceiling: what the whole job may use."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# ---- start-up cache: compiled circuit and synthetic witnesses on local disk, so that ranks
+# 1..N-1 (and the next run on the same box: the driver runs N = 1, 2, 4, 8 back to back) load what
+# one process already computed.  Files are this program's own output (pickle / .npy), written
+# atomically; a flock per file makes exactly one process compute each of them.
+def cache_dir():
+    d = os.environ.get("ZKMI_CACHE_DIR") or os.path.join(
+        os.environ.get("TMPDIR", "/tmp"), f"zkmi-cache-{os.getuid()}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _source_digest():
+    """hash of every Python source of the package: a code change invalidates the cache"""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "gnark_crypto_primitives_amd")
+    for dp, dn, fn in sorted(os.walk(pkg)):
+        dn.sort()
+        for f in sorted(fn):
+            if f.endswith(".py"):
+                h.update(f.encode())
+                h.update(open(os.path.join(dp, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cached(name, make, load, save, use_cache=True):
+    """-> (object, hit).  make() under an exclusive lock unless the file is already there."""
+    if not use_cache:
+        return make(), False
+    import fcntl
+    path = os.path.join(cache_dir(), name)
+    if os.path.exists(path):
+        try:
+            return load(path), True
+        except Exception:
+            pass
+    with open(path + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if os.path.exists(path):
+            try:
+                return load(path), True
+            except Exception:
+                pass
+        obj = make()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        save(tmp, obj)
+        os.replace(tmp, path)
+        return obj, False
+
+
+def compile_cached(workload, levels, populated, solver_lanes, use_cache=True):
+    """-> (CompiledCircuit, assignment generator, label, cache hit)"""
+    import pickle
+    from gnark_crypto_primitives_amd import workloads
+    from gnark_crypto_primitives_amd.frontend import compile_circuit
+    circuit, gen, label = workloads.build(workload, levels, populated)
+
+    def save(path, obj):
+        with open(path, "wb") as f:
+            pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def load(path):
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    cc, hit = cached(f"cc-{_source_digest()}-{workload}-{levels}-{solver_lanes}.pkl",
+                     lambda: compile_circuit(circuit, solver_lanes), load, save, use_cache)
+    return cc, gen, label, hit
+
+
 def _gen_chunk(job):
     workload, levels, populated, seed, count = job
     from gnark_crypto_primitives_amd import workloads
@@ -56,7 +144,21 @@ def _gen_chunk(job):
 _GEN_CC = None
 
 
-def generate_witnesses(cc, workload, levels, jobs, workers):
+def generate_witnesses(cc, workload, levels, jobs, workers, use_cache=True):
+    """jobs: [(name, seed, count, populated)] -> {name: [count, n_inputs, 4] uint64 array}; each
+    job's array is kept in the start-up cache (keyed by the circuit's fingerprint and the job)."""
+    out, fp = {}, cc.fingerprint()
+    for job in jobs:
+        name, seed, count, populated = job
+        out[name], _ = cached(
+            f"wit-{fp}-{workload}-{levels}-{populated}-{seed}-{count}.npy",
+            lambda: np.stack(_generate(cc, workload, levels, [job], workers)[name])
+            if count else np.zeros((0, cc.n_inputs, 4), np.uint64),
+            lambda p: np.load(p), lambda p, a: np.save(open(p, "wb"), a), use_cache)
+    return out
+
+
+def _generate(cc, workload, levels, jobs, workers):
     """jobs: [(name, seed, count, populated)] -> {name: [input arrays]}.  Chunks of 32 witnesses
     are dealt to a fork()ed process pool (off-circuit Poseidon in Python big ints is ~0.3 ms per
     hash: 1024 fully populated 160-level paths are 50 s on one core)."""
@@ -129,9 +231,108 @@ def bench_plonk(args):
     ctx.close()
 
 
+class stdout_to_stderr:
+    """RCCL / gloo print banners on fd 1 when a group comes up; stdout must carry the one JSON
+    line only, so fd 1 points at stderr inside this block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process (which has not touched the GPU
+    and never will) warms the start-up cache with every core of the host, then starts N fresh rank
+    processes of this same script -- children, not an exec -- and forwards rank 0's stdout."""
+    import socket
+    import subprocess
+    from gnark_crypto_primitives_amd import backend
+    n = args.gpus
+    t0 = time.time()
+    if args.backend == "groth16" and not args.no_cache:
+        cc, _, _, _ = compile_cached(args.workload, args.levels, args.populated, args.solver_lanes)
+        for r in range(n):
+            generate_witnesses(cc, args.workload, args.levels, rank_jobs(args, r, n),
+                               args.gen_workers or host_cpus())
+        if args.verbose:
+            print(f"launcher: start-up cache warm for {n} ranks ({time.time() - t0:.1f}s)",
+                  file=sys.stderr, flush=True)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    sys.exit(backend.launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                        n, port))
+
+
+def rank_jobs(args, rank, world):
+    """-> witness jobs [(name, seed, count, populated)] of one rank (seeded per rank)"""
+    from gnark_crypto_primitives_amd import backend
+    if args.scaling == "strong":
+        lo, hi = backend.shard_range(args.batch, rank, world)
+        B = hi - lo
+    else:
+        B = args.batch
+    n_distinct = min(B, args.distinct) if args.distinct > 0 else B
+    wc_steps = args.worst_case_steps if args.worst_case_steps >= 0 else args.steps
+    if args.workload != "arbo" or args.populated >= args.levels - 1:
+        wc_steps = 0
+    jobs = [("main", 1000 + rank, n_distinct, args.populated)]
+    if wc_steps:
+        jobs.append(("worst", 5000 + rank, B, args.levels - 1))
+    return jobs
+
+
+def rehearse(args, rank, world, B, global_batch, startup, t0, label):
+    """--rehearsal: the N-rank skeleton of a bench run without any GPU work (this is NOT a CPU
+    fallback of the prover: no proof is computed, `value` is null).  gloo process group, the same
+    barriers, K steps of the per-step all_gather on zeroed 264-byte records."""
+    import torch
+    import torch.distributed as dist
+    from gnark_crypto_primitives_amd import backend
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    with stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    world_seen = dist.get_world_size()
+    proofs = torch.zeros((B, 32), dtype=torch.int64)
+    proofs[:, 0] = rank                                     # so the gather's placement is checkable
+    status = torch.zeros(B, dtype=torch.int32)
+    startup["total_s"] = time.time() - t0
+    dist.barrier()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        gp, gs = backend.gather_proofs(proofs, status, global_batch, force=True)
+    dist.barrier()
+    elapsed = time.perf_counter() - ts
+    lo = backend.shard_range(global_batch, rank, world)[0] if args.scaling == "strong" else rank * B
+    ok = bool(gp.shape == (global_batch, 32) and bool((gp[lo:lo + B, 0] == rank).all()))
+    t = torch.tensor([int(ok)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"proofs/sec, {label}, Groth16/BN254", "value": None, "unit": "proofs/s",
+            "rehearsal": True, "n_gpus": world_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "data": "synthetic",
+            "config": {"workload": f"{label}, batch {B} proofs per GPU", "global_batch": global_batch,
+                       "parallelism": f"rehearsal: gloo process group of {world_seen} rank(s) as "
+                                      f"torch.distributed reports it, no GPU work"},
+            "gathered_on_every_rank": bool(t.item()), "startup_s": startup}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE if a launcher set it, "
+                         "else 1); N > 1 without a launcher starts the N rank processes itself")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
@@ -172,24 +373,42 @@ def main():
     ap.add_argument("--solver-lanes", type=int, default=0,
                     help="sub-lanes of the witness solver per proof (zkmi_cs_desc.lanes_per_proof); "
                          "0 = the frontend's choice (shortest schedule)")
+    ap.add_argument("--table-budget-gb", type=float, default=0.0,
+                    help="zkmi_pk_desc.table_budget_bytes: cap for the key's MSM tables (0 = "
+                         "whatever the free HBM allows); the bounded-memory operating points")
+    ap.add_argument("--no-cache", action="store_true",
+                    help="recompute the compiled circuit and the witnesses instead of using the "
+                         "start-up cache ($ZKMI_CACHE_DIR, default $TMPDIR/zkmi-cache-<uid>)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="launcher / process-group rehearsal for boxes without a GPU: everything "
+                         "but the GPU work (compile, witnesses, rendezvous, barriers, per-step "
+                         "all_gather of zeroed records); prints value null and \"rehearsal\": true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        return launch_ranks(args)
+    if env_world is not None and args.gpus is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} disagrees with the inherited WORLD_SIZE={env_world}")
     if args.backend == "plonk":
+        if int(env_world or 1) != 1:
+            sys.exit("bench.py: --backend plonk is a one-GPU secondary number")
         return bench_plonk(args)
 
     from gnark_crypto_primitives_amd import backend, workloads
-    from gnark_crypto_primitives_amd.frontend import compile_circuit
     from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
 
     rank, world, local_rank = backend.env_rank_world()
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) \
         else (lambda *a: None)
     t0 = time.time()
-    circuit, gen, label = workloads.build(args.workload, args.levels, args.populated)
-    cc = compile_circuit(circuit, args.solver_lanes)
+    use_cache = not args.no_cache
+    cc, gen, label, cc_hit = compile_cached(args.workload, args.levels, args.populated,
+                                            args.solver_lanes, use_cache)
+    startup = {"compile_s": time.time() - t0, "compile_cache_hit": cc_hit}
     log(f"compiled: {cc.n_constraints} constraints, {cc.n_wires} wires, {cc.n_ops} ops in "
         f"{cc.v_n_steps} steps x {cc.lanes_per_proof} lanes "
-        f"({time.time() - t0:.1f}s)")
+        f"({time.time() - t0:.1f}s, cache {'hit' if cc_hit else 'miss'})")
 
     # ---- synthetic witnesses, seeded per rank, generated by worker processes
     # BEFORE this process touches the GPU (nothing is forked once HIP is initialised)
@@ -199,14 +418,13 @@ def main():
     else:
         B, global_batch = args.batch, args.batch * world
     n_distinct = min(B, args.distinct) if args.distinct > 0 else B
-    wc_steps = args.worst_case_steps if args.worst_case_steps >= 0 else args.steps
-    if args.workload != "arbo" or args.populated >= args.levels - 1:
-        wc_steps = 0
-    jobs = [("main", 1000 + rank, n_distinct, args.populated)]
-    if wc_steps:
-        jobs.append(("worst", 5000 + rank, B, args.levels - 1))
+    jobs = rank_jobs(args, rank, world)
+    wc_steps = (args.worst_case_steps if args.worst_case_steps >= 0 else args.steps) \
+        if len(jobs) > 1 else 0
+    t1 = time.time()
     sets = generate_witnesses(cc, args.workload, args.levels, jobs, args.gen_workers or
-                              max(1, available_cpus() // max(1, min(world, 8))))
+                              max(1, min(16, host_cpus() // world)), use_cache)
+    startup["witness_s"] = time.time() - t1
     ws = sets["main"]
     inp_h = np.stack([ws[i % n_distinct] for i in range(B)]) if B else \
         np.zeros((0, cc.n_inputs, 4), np.uint64)
@@ -217,6 +435,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.rehearsal:
+        return rehearse(args, rank, world, B, global_batch, startup, t0, label)
     from gnark_crypto_primitives_amd import groth16, lib
 
     if args.device >= 0:
@@ -228,12 +448,7 @@ def main():
     if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # RCCL prints a version banner on stdout at its first collective; stdout must carry the one
-        # JSON line only, so fd 1 points at stderr until the group is up
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             if args.dist_backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
             else:
@@ -244,17 +459,21 @@ def main():
             dist.all_reduce(t)
             if cdev.type == "cuda":
                 torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
 
+    world_seen = dist.get_world_size() if pg else 1
+    if world_seen != world:
+        sys.exit(f"bench.py: process group has {world_seen} ranks, WORLD_SIZE says {world}")
+    t1 = time.time()
     ctx = lib.Context(local_rank)
     pk, vk, _ = groth16.setup(cc, 2, groth16.gpu_mul(ctx))
+    startup["setup_s"] = time.time() - t1
     log(f"setup: log_n={pk.log_n} A={len(pk.a_wire)} B={len(pk.b_wire)} K={len(pk.k_wire)} "
         f"Z={pk.g1_z.shape[0]} ({time.time() - t0:.1f}s)")
+    t1 = time.time()
     prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2, max_batch=max(B, 64),
-                            msm_chunk_factor=args.msm_chunk_factor)
+                            msm_chunk_factor=args.msm_chunk_factor,
+                            table_budget_bytes=int(args.table_budget_gb * 1e9))
+    startup["key_load_s"] = time.time() - t1
     log(f"key resident, window tables built ({time.time() - t0:.1f}s)")
 
     def to_dev(a):
@@ -313,6 +532,7 @@ def main():
             elapsed = float(t.item())
         return elapsed, stage
 
+    startup["total_s"] = time.time() - t0
     # Steps are software-pipelined two deep through the library's submit/collect pair: the
     # latency-bound witness solve of step k+1 (16 wavefronts) runs on a second HIP stream under the
     # NTT/MSM kernels of step k.  The timed region contains K submits and K collects: the first
@@ -418,7 +638,8 @@ def main():
             "metric": "proofs/sec, Arbo-160 Poseidon SMT-verifier circuit, Groth16/BN254"
                       if args.workload == "arbo" and args.levels == 160
                       else f"proofs/sec, {label}, Groth16/BN254",
-            "value": global_batch * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
+            "value": global_batch * args.steps / elapsed, "unit": "proofs/s",
+            "n_gpus": world_seen,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "u32x8 Montgomery (254-bit integer)",
@@ -433,7 +654,7 @@ def main():
                        "global_batch": global_batch,
                        "parallelism": (f"batch-split x{world} ({args.scaling} scaling), "
                                        f"{args.dist_backend if pg else 'no'} process group "
-                                       f"of {world} rank(s)"
+                                       f"of {world_seen} rank(s) as torch.distributed reports it"
                                        + (", all_gather of 264-B proof records per step"
                                           if gather else ", no collective in the data path"))},
             "gathered_on_every_rank": gather_ok,
@@ -444,6 +665,7 @@ def main():
                          "msm_g2": stage[3], "assemble_overlapped": stage[4], "main_stream_span": stage[5],
                          "msm_g1_kernel_only": stage[6], "msm_g2_kernel_only": stage[7]},
             "unsatisfied": n_bad,
+            "startup_s": startup,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -84,3 +84,65 @@ def prove_sharded(prover_fn, inputs: np.ndarray, rs: np.ndarray, device=None):
     else:
         proofs, status = np.zeros((0, 32), np.uint64), np.zeros(0, np.int32)
     return gather_proofs(proofs, status, batch, device)
+
+
+def launch_local_ranks(argv, n_ranks: int, port: int, extra_env=None) -> int:
+    """Start ``n_ranks`` fresh processes of ``argv`` on this node, one per GPU, with the
+    torch.distributed environment a launcher would give them (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR = 127.0.0.1, MASTER_PORT).  Children, never an exec: the caller keeps running (it
+    must not have initialised HIP itself), forwards rank 0's stdout to its own stdout, sends the
+    other ranks' stdout to stderr, and returns 0 or the first non-zero exit code -- in which case
+    the ranks still running are terminated by PID (a dead rank would leave the others waiting in
+    a collective for ever)."""
+    import subprocess
+    import sys
+    import time
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        out0 = procs[0].stdout
+        os.set_blocking(out0.fileno(), False)
+        live = set(range(n_ranks))
+        while live:
+            chunk = out0.read() if not out0.closed else None
+            if chunk:
+                sys.stdout.buffer.write(chunk)
+                sys.stdout.buffer.flush()
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"launch_local_ranks: rank {r} exited with {code}; stopping the others",
+                              file=sys.stderr, flush=True)
+            if rc:
+                break
+            if live:
+                time.sleep(0.05)
+        if rc:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        os.set_blocking(out0.fileno(), True)
+        rest = out0.read()
+        if rest:
+            sys.stdout.buffer.write(rest)
+            sys.stdout.buffer.flush()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
