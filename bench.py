@@ -373,6 +373,15 @@ def main():
     ap.add_argument("--solver-lanes", type=int, default=0,
                     help="sub-lanes of the witness solver per proof (zkmi_cs_desc.lanes_per_proof); "
                          "0 = the frontend's choice (shortest schedule)")
+    ap.add_argument("--entry", choices=("inputs", "witness", "witness-abc"), default="inputs",
+                    help="inputs: zkmi_prove_submit on device-resident circuit inputs (the headline). "
+                         "witness / witness-abc: the gnark drop-in entry, zkmi_prove_witness_submit "
+                         "from HOST memory every step -- solved wire vectors only (R1CS matrices "
+                         "resident, a, b, c formed on the device) / wire vectors + a + b + c; the "
+                         "timed region then includes the PCIe transfer")
+    ap.add_argument("--host-mem", choices=("pageable", "pinned"), default="pageable",
+                    help="--entry witness*: where the solved witnesses live (pinned = zkmi_host_alloc)")
+    ap.add_argument("--copy-threads", type=int, default=0, help="zkmi_set_copy_threads (0 = default)")
     ap.add_argument("--table-budget-gb", type=float, default=0.0,
                     help="zkmi_pk_desc.table_budget_bytes: cap for the key's MSM tables (0 = "
                          "whatever the free HBM allows); the bounded-memory operating points")
@@ -420,7 +429,7 @@ def main():
     n_distinct = min(B, args.distinct) if args.distinct > 0 else B
     jobs = rank_jobs(args, rank, world)
     wc_steps = (args.worst_case_steps if args.worst_case_steps >= 0 else args.steps) \
-        if len(jobs) > 1 else 0
+        if len(jobs) > 1 and args.entry == "inputs" else 0
     t1 = time.time()
     sets = generate_witnesses(cc, args.workload, args.levels, jobs, args.gen_workers or
                               max(1, min(16, host_cpus() // world)), use_cache)
@@ -485,6 +494,35 @@ def main():
     log(f"witnesses resident ({time.time() - t0:.1f}s)")
     gather = pg and not args.no_gather
     gathered = [None]
+    wit = None
+    if args.entry != "inputs" and B:
+        # solved witnesses in host memory, as gnark's solver would leave them (untimed set-up: the
+        # GPU solver's output copied out once)
+        t1 = time.time()
+        status, W, abc = prover.solve(inp_h, want_wires=True, want_abc=args.entry == "witness-abc")
+        assert not status.any()
+        arrs = [W] + ([abc[0], abc[1], abc[2]] if abc is not None else [])
+        if args.host_mem == "pinned":
+            pinned = []
+            for x in arrs:
+                y = ctx.host_alloc(x.shape)
+                y[...] = x
+                pinned.append(y)
+            arrs = pinned
+        if args.copy_threads:
+            ctx.set_copy_threads(args.copy_threads)
+        if args.entry == "witness":
+            prover.load_r1cs()
+        wit = arrs
+        startup["witness_solve_s"] = time.time() - t1
+        log(f"solved witnesses on the host: {sum(x.nbytes for x in arrs) / 1e9:.2f} GB "
+            f"({args.host_mem}) ({time.time() - t0:.1f}s)")
+
+    def submit(inp, rsd):
+        if wit is None:
+            prover.submit(inp, rsd)
+        else:
+            prover.submit_witness(wit[0], rs_h, *wit[1:])
 
     def finish_step():
         """the path's only exchange: all_gather of this step's proof records (RCCL on device
@@ -511,14 +549,18 @@ def main():
                 finish_step()
         elif args.no_pipeline:
             for _ in range(steps):
-                prover.prove(inp, rsd, proofs_d, status_d)
+                if wit is None:
+                    prover.prove(inp, rsd, proofs_d, status_d)
+                else:
+                    submit(inp, rsd)
+                    prover.collect(proofs_d, status_d)
                 stage += np.array(ctx.last_timings())
                 finish_step()
         else:
-            prover.submit(inp, rsd)
+            submit(inp, rsd)
             for k in range(steps):
                 if k + 1 < steps:
-                    prover.submit(inp, rsd)
+                    submit(inp, rsd)
                 prover.collect(proofs_d, status_d)
                 stage += np.array(ctx.last_timings())
                 finish_step()
@@ -538,8 +580,11 @@ def main():
     # NTT/MSM kernels of step k.  The timed region contains K submits and K collects: the first
     # solve is exposed, nothing of the timed work happens outside the region.
     for _ in range(args.warmup):
-        if B:
+        if B and wit is None:
             prover.prove(inp_d, rs_d, proofs_d, status_d)
+        elif B:
+            submit(inp_d, rs_d)
+            prover.collect(proofs_d, status_d)
         finish_step()
     elapsed, stage = timed_steps(args.steps, inp_d, rs_d)
     status = status_d.cpu().numpy()
@@ -661,6 +706,14 @@ def main():
             "value_worst_case": worst["value"] if worst else None,
             "worst_case": worst,
             "pipelined": not args.no_pipeline,
+            "entry": {"inputs": "zkmi_prove_submit (circuit inputs resident in HBM)",
+                      "witness": "zkmi_prove_witness_submit, wire vectors from host memory, "
+                                 "a, b, c formed on the device (zkmi_r1cs_load)",
+                      "witness-abc": "zkmi_prove_witness_submit, W + a + b + c from host memory"
+                      }[args.entry],
+            "host_transfer": None if wit is None else {
+                "memory": args.host_mem, "bytes_per_step": int(sum(x.nbytes for x in wit)),
+                "GB_per_s_if_serial": sum(x.nbytes for x in wit) / 1e9 / (elapsed / args.steps)},
             "stage_ms": {"solve": stage[0], "quotient_ntt": stage[1], "msm_g1": stage[2],
                          "msm_g2": stage[3], "assemble_overlapped": stage[4], "main_stream_span": stage[5],
                          "msm_g1_kernel_only": stage[6], "msm_g2_kernel_only": stage[7]},

@@ -300,6 +300,7 @@ void zkmi_destroy(zkmi_ctx* ctx) {
   }
   for (auto& s : ctx->scratch)
     if (s.p) hipFree(s.p);
+  witness_ring_free(ctx);
   for (auto& e : ctx->ev)
     if (e) hipEventDestroy(e);
   for (auto& e : ctx->part_ev)
@@ -479,7 +480,10 @@ static double prove_working_set_bytes(uint32_t log_n, size_t n_slots, size_t n_i
   const double sint = (double)n_msm_max * Bp * 32;
   const double partials = 2 * 21.0 * 254 * Bp * 256;
   const double sums = 2 * Bp * (7 * 128 + 2 * 256 + 256 + 256.0 * (4 * 128 + 256));
-  return 2 * set + n * Bp * 32 + digits + sint + partials + sums + 2e9 + 1e9;
+  // device half of the witness entry's staging ring (witness.hip): three chunks of ~64 MB, or of
+  // one 64-proof column block of the wire matrix when that is larger (n_in = n_wires here)
+  const double ring = 3.0 * std::max(68e6, (double)n_in * 32 * 64);
+  return 2 * set + n * Bp * 32 + digits + sint + partials + sums + ring + 2e9 + 1e9;
 }
 static double free_hbm_bytes() {
   size_t free_b = 0, total_b = 0;
@@ -1289,77 +1293,6 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
   int rc = zkmi_prove_submit(ctx, pk, cs, inputs, batch, rs);
   if (rc) return rc;
   return zkmi_prove_collect(ctx, proofs_out, status_out);
-}
-
-// Stage 1 replaced by the caller's own solver: wires and a, b, c arrive solved, in gnark's image.
-int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires, const void* a,
-                             const void* b, const void* c, size_t n_constraints, size_t batch,
-                             const void* rs, void* proofs_out) {
-  ZK_HIP(hipSetDevice(ctx->device));
-  if (batch == 0) return ZKMI_OK;
-  if (any_pending(ctx)) {
-    ctx->err = "prove_witness_batch: batches submitted with zkmi_prove_submit are still in flight";
-    return ZKMI_ERR_ARG;
-  }
-  if (!pk || !wires || !a || !b || !c || !rs || !proofs_out) {
-    ctx->err = "prove_witness_batch: null argument";
-    return ZKMI_ERR_ARG;
-  }
-  const size_t n = (size_t)1 << pk->log_n;
-  if (n_constraints == 0 || n_constraints > n) {
-    ctx->err = "prove_witness_batch: n_constraints must be in [1, 2^log_n]";
-    return ZKMI_ERR_ARG;
-  }
-  const int si = ctx->next_submit;
-  zkmi_ctx::ProveSet& S = ctx->sets[si];
-  const size_t Bp = round_up(batch, 64);
-  const size_t nw = pk->n_wires;
-  int rc;
-  const int base = si == 0 ? 0 : 8;
-  void* misc;
-  if ((rc = ensure_scratch(ctx, si == 0 ? 14 : 15,
-                           Bp * (7 * 128 + 2 * 256 + 256 + 256 * (4 * 128 + 256)), &S.sums)) ||
-      (rc = ensure_scratch(ctx, base + 0, nw * Bp * 32, &S.slots)) ||
-      (rc = ensure_scratch(ctx, base + 1, n * Bp * 32, &S.a)) ||
-      (rc = ensure_scratch(ctx, base + 2, n * Bp * 32, &S.b)) ||
-      (rc = ensure_scratch(ctx, base + 3, n * Bp * 32, &S.c)) ||
-      (rc = ensure_scratch(ctx, base + 5, Bp * (96 + 4), &misc)))
-    return rc;
-  S.rs = misc;
-  S.st = (char*)misc + Bp * 96;
-  S.heavy_enqueued = false;
-  {
-    // proof-major host or device buffers -> batch-inner rows, on the second stream like a submit
-    Staged sw(ctx), sa(ctx), sb(ctx), sc(ctx), sr(ctx);
-    hipStream_t saved = ctx->stream;
-    ctx->stream = ctx->stream2;
-    hipEventRecord(S.ev0, ctx->stream);
-    rc = sw.in(wires, batch * nw * 32);
-    if (!rc) rc = sa.in(a, batch * n_constraints * 32);
-    if (!rc) rc = sb.in(b, batch * n_constraints * 32);
-    if (!rc) rc = sc.in(c, batch * n_constraints * 32);
-    if (!rc) rc = sr.in(rs, batch * 64);
-    if (!rc) rc = transpose_in(ctx, sw.dev, S.slots, nw, batch, Bp, 32);
-    if (!rc) rc = transpose_in(ctx, sa.dev, S.a, n_constraints, batch, Bp, 32);
-    if (!rc) rc = transpose_in(ctx, sb.dev, S.b, n_constraints, batch, Bp, 32);
-    if (!rc) rc = transpose_in(ctx, sc.dev, S.c, n_constraints, batch, Bp, 32);
-    if (!rc) rc = transpose_in(ctx, sr.dev, S.rs, 2, batch, Bp, 32);
-    if (!rc && hipMemsetAsync(S.st, 0, Bp * 4, ctx->stream) != hipSuccess) rc = ZKMI_ERR_HIP;
-    hipEventRecord(S.ev1, ctx->stream);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = ZKMI_ERR_HIP;  // staging buffers go away
-    ctx->stream = saved;
-    if (rc) return rc;
-  }
-  S.pending = true;
-  S.batch = batch;
-  S.Bp = Bp;
-  S.pk = pk;
-  S.cs = nullptr;
-  S.n_constraints = n_constraints;
-  S.f_domain = false;
-  ctx->next_submit ^= 1;
-  std::vector<int32_t> status(batch);
-  return zkmi_prove_collect(ctx, proofs_out, status.data());
 }
 
 int zkmi_last_timings(zkmi_ctx* ctx, double* ms_out) {

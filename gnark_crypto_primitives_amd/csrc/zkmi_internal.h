@@ -85,6 +85,17 @@ struct zkmi_ctx {
   hipEvent_t part_ev[2] = {}, acc_ev[2] = {};
   bool part_ev_valid[2] = {false, false};
   unsigned part_next = 0;
+  // witness entry (witness.hip): ring of three pinned host chunks + three device chunks through
+  // which proof-major host arrays stream in (done[i]: the transpose that consumed chunk i)
+  struct StageRing {
+    void* pinned[3] = {};
+    void* dev[3] = {};
+    hipEvent_t done[3] = {};
+    bool busy[3] = {false, false, false};
+    size_t bytes = 0;
+    unsigned next = 0;
+  } ring;
+  int copy_threads = 0;   // host threads that fill a pinned chunk from pageable memory; 0 = 4
 };
 
 // Window plan of a fixed-base table: W windows whose sizes sum to exactly 255 bits (scalars are
@@ -183,6 +194,10 @@ enum { OP_END = 0, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_
 static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 int ensure_scratch(zkmi_ctx* ctx, int slot, size_t bytes, void** out);
+// where a caller's pointer lives (hipPointerGetAttributes)
+enum { PTR_PAGEABLE = 0, PTR_PINNED = 1, PTR_DEVICE = 2 };
+int pointer_kind(const void* p);
+void witness_ring_free(zkmi_ctx* ctx);
 
 // layout conversion (proof-major <-> batch-inner), rows x batch elements of `elem_bytes`
 int transpose_in(zkmi_ctx* ctx, const void* src_pm, void* dst_bi, size_t rows, size_t batch,

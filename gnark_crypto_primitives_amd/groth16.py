@@ -201,7 +201,28 @@ class Prover:
                          else int(sparse_witness))
         self.pk_h = ctx.pk_load(pd)
 
+    def load_r1cs(self):
+        """zkmi_r1cs_load of the circuit's L, R, O (gnark: constraint.R1CS terms {CID, VID} and
+        cs.Coefficients): afterwards ``submit_witness`` ships wire vectors only."""
+        if getattr(self, "r1cs_h", None):
+            return self.r1cs_h
+        cc = self.cc
+        coeffs = to_mont_array(cc.consts)
+        keep = [coeffs]
+        fields = []
+        for ptr, col, cid in (cc.L, cc.Rm, cc.O):
+            terms = np.ascontiguousarray(np.stack([cid, col], axis=1).astype(np.uint32))
+            ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
+            keep += [ptr, terms]
+            fields += [ptr.ctypes.data, terms.ctypes.data]
+        rd = _lib.R1csDesc(cc.n_wires, cc.n_constraints, len(cc.consts), coeffs.ctypes.data, *fields)
+        self.r1cs_h = self.ctx.r1cs_load(rd)
+        return self.r1cs_h
+
     def close(self):
+        if getattr(self, "r1cs_h", None):
+            self.ctx.r1cs_free(self.r1cs_h)
+            self.r1cs_h = None
         if getattr(self, "pk_h", None):
             self.ctx.pk_free(self.pk_h)
             self.pk_h = None
@@ -245,6 +266,26 @@ class Prover:
         self.ctx.prove_witness_batch(self.pk_h, wires, a, b, c, self.cc.n_constraints, batch, rs,
                                      proofs_out)
         return proofs_out
+
+    def submit_witness(self, wires, rs, a=None, b=None, c=None):
+        """Stage 1 of a prove from solved witnesses (zkmi_prove_witness_submit); ``collect`` returns
+        the proofs.  Without a, b, c the R1CS matrices are loaded (once) and the device forms them
+        from the wire vectors and checks a.b = c per proof."""
+        batch = wires.shape[0]
+        self._check_batch(wires, (batch, self.cc.n_wires, 4), "wires")
+        self._check_batch(rs, (batch, 2, 4), "rs")
+        if a is None:
+            if b is not None or c is not None:
+                raise ValueError("a, b, c: all three or none")
+            self.ctx.prove_witness_submit(self.pk_h, self.load_r1cs(), wires, None, None, None, 0,
+                                          batch, rs)
+        else:
+            for name, x in (("a", a), ("b", b), ("c", c)):
+                self._check_batch(x, (batch, self.cc.n_constraints, 4), name)
+            self.ctx.prove_witness_submit(self.pk_h, None, wires, a, b, c, self.cc.n_constraints,
+                                          batch, rs)
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append(((wires, a, b, c), rs, batch))      # keep buffers alive
 
     @staticmethod
     def _check_batch(x, shape, name):

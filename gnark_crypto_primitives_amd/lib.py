@@ -39,6 +39,13 @@ class CsDesc(C.Structure):
                 ("consts", C.c_void_p)]
 
 
+class R1csDesc(C.Structure):
+    _fields_ = [("n_wires", C.c_uint32), ("n_constraints", C.c_uint32), ("n_coeffs", C.c_uint32),
+                ("coeffs", C.c_void_p), ("l_ptr", C.c_void_p), ("l_terms", C.c_void_p),
+                ("r_ptr", C.c_void_p), ("r_terms", C.c_void_p), ("o_ptr", C.c_void_p),
+                ("o_terms", C.c_void_p)]
+
+
 # every symbol include/zkmi.h declares: (name, restype, argtypes)
 _P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
 SYMBOLS = [
@@ -65,6 +72,12 @@ SYMBOLS = [
     ("zkmi_prove_submit", _I, [_P, _P, _P, _P, _SZ, _P]),
     ("zkmi_prove_collect", _I, [_P, _P, _P]),
     ("zkmi_prove_witness_batch", _I, [_P, _P, _P, _P, _P, _P, _SZ, _SZ, _P, _P]),
+    ("zkmi_host_alloc", _P, [_P, _SZ]),
+    ("zkmi_host_free", None, [_P, _P]),
+    ("zkmi_set_copy_threads", _I, [_P, _I]),
+    ("zkmi_r1cs_load", _I, [_P, C.POINTER(R1csDesc), C.POINTER(_P)]),
+    ("zkmi_r1cs_free", None, [_P, _P]),
+    ("zkmi_prove_witness_submit", _I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _SZ, _P]),
     ("zkmi_last_timings", _I, [_P, C.POINTER(C.c_double)]),
     ("zkmi_plonk_pk_load", _I, [_P, _P, C.POINTER(_P)]),
     ("zkmi_plonk_pk_free", None, [_P, _P]),
@@ -79,7 +92,9 @@ _lib = None
 
 
 def load():
-    """dlopen libzkmi.so and bind every declared symbol; raises if the library is missing."""
+    """dlopen libzkmi.so and bind every declared symbol; raises if the library is missing.
+    A process that also uses torch on the GPU must import torch BEFORE this call: torch ships its
+    own libamdhip64.so.7, and the HIP runtime loaded first serves every later library."""
     global _lib
     if _lib is not None:
         return _lib
@@ -237,6 +252,39 @@ class Context:
                                                       _ptr(c), n_constraints, batch, _ptr(rs),
                                                       _ptr(proofs_out)),
                     "zkmi_prove_witness_batch")
+
+    def prove_witness_submit(self, pk_h, r1cs_h, wires, a, b, c, n_constraints, batch, rs):
+        self._check(self.lib.zkmi_prove_witness_submit(self.h, pk_h, r1cs_h, _ptr(wires), _ptr(a),
+                                                       _ptr(b), _ptr(c), n_constraints, batch,
+                                                       _ptr(rs)), "zkmi_prove_witness_submit")
+
+    def r1cs_load(self, desc: "R1csDesc"):
+        h = C.c_void_p()
+        self._check(self.lib.zkmi_r1cs_load(self.h, C.byref(desc), C.byref(h)), "zkmi_r1cs_load")
+        return h
+
+    def r1cs_free(self, h):
+        self.lib.zkmi_r1cs_free(self.h, h)
+
+    def host_alloc(self, shape, dtype=np.uint64):
+        """numpy array over page-locked memory from zkmi_host_alloc (free with host_free)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.zkmi_host_alloc(self.h, nbytes)
+        if not p:
+            raise ZkmiError(f"zkmi_host_alloc({nbytes}) failed")
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.zkmi_host_free(self.h, p)
+
+    def set_copy_threads(self, n):
+        self._check(self.lib.zkmi_set_copy_threads(self.h, n), "zkmi_set_copy_threads")
 
     def last_timings(self):
         arr = (C.c_double * 8)()

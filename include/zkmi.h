@@ -192,21 +192,6 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
 int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                      size_t batch, const void* rs, void* proofs_out, int32_t* status_out);
 
-/* Groth16 prove from SOLVED witnesses: the entry point for a caller that keeps gnark's own
- * solver (cs.Solve -> solution.W, solution.A, solution.B, solution.C) and hands quotient, MSMs and
- * assembly to the GPU -- what gnark's icicle backend does [UPSTREAM-RECALL, SURVEY.md §3.2, §8b].
- * No zkmi_cs is needed.
- *   wires: batch x pk.n_wires fr elements (Montgomery, gnark's image), proof-major: the full wire
- *          vector including the ONE wire at index 0
- *   a, b, c: batch x n_constraints fr elements each (<L_k,w>, <R_k,w>, <O_k,w>); the library pads
- *          to the domain
- *   rs, proofs_out: as zkmi_prove_batch
- * Blocking; same streams and scratch as zkmi_prove_batch (returns ZKMI_ERR_ARG while submitted
- * batches are in flight). */
-int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires, const void* a,
-                             const void* b, const void* c, size_t n_constraints, size_t batch,
-                             const void* rs, void* proofs_out);
-
 /* The same prove split in two so that consecutive batches overlap: `submit` stages the inputs and
  * runs the witness solve on a second HIP stream, `collect` runs quotient + MSMs + assembly of the
  * OLDEST submitted batch and blocks until its proofs are written.  At most two batches may be in
@@ -218,6 +203,67 @@ int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires
 int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                       size_t batch, const void* rs);
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
+
+/* -- the gnark drop-in entry: prove from SOLVED witnesses --------------------------------------- */
+/* For a caller that keeps gnark's own solver (cs.Solve -> solution.W, and optionally solution.A,
+ * .B, .C) and hands quotient, MSMs and assembly to the GPU -- the place of groth16.Prove(ccs, pk,
+ * fullWitness) (reference call sites: tree/test/verifier_bn254_test.go:41,67; what gnark's icicle
+ * backend accelerates [UPSTREAM-RECALL, SURVEY.md §3.2, §8b]).  No zkmi_cs is needed.
+ *
+ * Page-locked host memory for the batch arrays.  A shim assembles a batch from per-proof witness
+ * vectors anyway; assembling it in memory from zkmi_host_alloc lets the DMA engine read it in place
+ * (no staging copy, truly asynchronous submit).  Ordinary (pageable) memory is accepted everywhere
+ * and staged through a ring of pinned chunks owned by the context. */
+void* zkmi_host_alloc(zkmi_ctx* ctx, size_t bytes);
+void zkmi_host_free(zkmi_ctx* ctx, void* p);
+/* Host threads that copy pageable memory into the pinned ring (0 = default 4). */
+int zkmi_set_copy_threads(zkmi_ctx* ctx, int threads);
+
+/* The R1CS matrices, so that a caller ships the wire vector only and a = L.w, b = R.w, c = O.w are
+ * formed on the GPU ("zkmi_cs_load ... CSR A,B,C").  Mirrors gnark's
+ * constraint.R1CS [UPSTREAM-RECALL]: a coefficient table (cs.Coefficients, fr Montgomery) and, per
+ * constraint, three linear expressions of terms {coefficient index, wire index} (constraint.Term
+ * {CID, VID}); *_ptr are n_constraints + 1 offsets into the term arrays, starting at 0. */
+typedef struct {
+  uint32_t coeff; /* index into coeffs */
+  uint32_t wire;  /* column: 0 = ONE, then public, secret, internal wires */
+} zkmi_term;
+typedef struct {
+  uint32_t n_wires, n_constraints, n_coeffs;
+  const void* coeffs; /* n_coeffs fr elements, Montgomery, reduced */
+  const uint32_t* l_ptr;
+  const zkmi_term* l_terms;
+  const uint32_t* r_ptr;
+  const zkmi_term* r_terms;
+  const uint32_t* o_ptr;
+  const zkmi_term* o_terms;
+} zkmi_r1cs_desc;
+typedef struct zkmi_r1cs zkmi_r1cs;
+/* Validates every index on the host, copies the matrices to the device; host buffers may be freed
+ * afterwards. */
+int zkmi_r1cs_load(zkmi_ctx* ctx, const zkmi_r1cs_desc* desc, zkmi_r1cs** out);
+void zkmi_r1cs_free(zkmi_ctx* ctx, zkmi_r1cs* r1cs);
+
+/* Stage 1 of a prove from solved witnesses; the matching zkmi_prove_collect returns the proofs.
+ * Pipelines exactly like zkmi_prove_submit (two batches in flight, same streams, same HBM plan):
+ * batch k+1 streams in over PCIe underneath batch k's MSM kernels.
+ *   wires: batch x pk.n_wires fr elements (Montgomery, gnark's image), proof-major: the full wire
+ *          vector including the ONE wire at index 0; 16-byte aligned
+ *   r1cs != NULL: a = b = c = NULL, n_constraints = 0 or the loaded system's; the device forms
+ *          a, b, c and checks a.b = c (per-proof ZKMI_ERR_UNSATISFIED in collect's status_out)
+ *   r1cs == NULL: a, b, c: batch x n_constraints fr elements each (<L_k,w>, <R_k,w>, <O_k,w>,
+ *          solution.A/B/C); taken as they are (status_out = 0); the library pads to the domain
+ *   rs: batch x 2 fr, as zkmi_prove_batch
+ * Pageable host arrays have been consumed when the call returns; page-locked and device arrays
+ * must stay valid until the matching collect. */
+int zkmi_prove_witness_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_r1cs* r1cs,
+                              const void* wires, const void* a, const void* b, const void* c,
+                              size_t n_constraints, size_t batch, const void* rs);
+/* Blocking form: zkmi_prove_witness_submit(r1cs = NULL) + zkmi_prove_collect (returns
+ * ZKMI_ERR_ARG while submitted batches are in flight). */
+int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires, const void* a,
+                             const void* b, const void* c, size_t n_constraints, size_t batch,
+                             const void* rs, void* proofs_out);
 
 /* -- PLONK (BASELINE config 5 names this backend) ----------------------------------------------- */
 /* Stands in for plonk.Prove of gnark backend/plonk/bn254 [UPSTREAM-RECALL]: KZG commitments over

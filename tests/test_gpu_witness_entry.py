@@ -1,0 +1,177 @@
+"""The gnark drop-in entry: zkmi_prove_witness_submit / zkmi_prove_collect fed
+with SOLVED witnesses, as a cgo shim around groth16.Prove(ccs, pk, fullWitness) would
+(tree/test/verifier_bn254_test.go:41,67).  Both forms -- wire vectors only with the R1CS matrices
+resident (zkmi_r1cs_load), and W + a + b + c from the caller's solver -- from pageable host memory,
+page-locked memory (zkmi_host_alloc) and device memory, pipelined two deep, against the C oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from gnark_crypto_primitives_amd import circuits, groth16, lib
+from gnark_crypto_primitives_amd.frontend import compile_circuit
+from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+from gnark_crypto_primitives_amd.tree import smt_witness
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _solved(cc, inp):
+    """the C oracle's gnark-style solver: W, a, b, c per proof"""
+    from oracle import cref
+    rh = cref.R1csHandle(cc)
+    sol = [cref.r1cs_solve(rh, inp[i]) for i in range(inp.shape[0])]
+    assert all(s[0] == 0 for s in sol)
+    return tuple(np.stack([s[k] for s in sol]) for k in (1, 2, 3, 4))
+
+
+@pytest.mark.parametrize("wbits", [(7, 5), (0, 0), (310, 309)])
+def test_witness_submit_small_all_memory_kinds(zk_ctx, wbits):
+    import torch
+    from oracle import cref
+    cc = compile_circuit(circuits.smt_inclusion_circuit(10))
+    pk, vk, td = groth16.setup(cc, 51, groth16.gpu_mul(zk_ctx))
+    rng = random.Random(51)
+    prover = groth16.Prover(zk_ctx, cc, pk, *wbits, gnark_key_layout=True)
+    rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
+    try:
+        for batch in (1, 63, 65, 130):
+            ws = [smt_witness.synthetic_inclusion(rng, 10, 1 + i % 9) for i in range(batch)]
+            inp = np.stack([to_mont_array(cc.assignment_vector(w)) for w in ws])
+            rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)])
+                           for _ in range(batch)])
+            W, A, B, Cc = _solved(cc, inp)
+            want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp, rs)
+            assert not wstatus.any()
+            # pageable host memory, both forms, two batches in flight
+            prover.submit_witness(W, rs)
+            prover.submit_witness(W, rs, A, B, Cc)
+            p1, s1 = prover.collect()
+            p2, s2 = prover.collect()
+            assert not s1.any() and not s2.any()
+            assert np.array_equal(p1, want) and np.array_equal(p2, want), (wbits, batch)
+            # page-locked memory from zkmi_host_alloc: read in place by the DMA engine
+            Wp = zk_ctx.host_alloc(W.shape)
+            Wp[...] = W
+            prover.submit_witness(Wp, rs)
+            p3, s3 = prover.collect()
+            zk_ctx.host_free(Wp)
+            assert not s3.any() and np.array_equal(p3, want)
+            # device memory
+            dev = torch.device("cuda", 0)
+            Wd, Ad, Bd, Cd = (torch.from_numpy(x.view(np.int64)).to(dev) for x in (W, A, B, Cc))
+            prover.submit_witness(Wd, rs, Ad, Bd, Cd)
+            prover.submit_witness(Wd, rs)
+            p4, _ = prover.collect()
+            p5, s5 = prover.collect()
+            assert np.array_equal(p4, want) and np.array_equal(p5, want) and not s5.any()
+            # the blocking round-2 entry is the same path
+            assert np.array_equal(prover.prove_witness(W, A, B, Cc, rs), want)
+            # a wire vector that does not satisfy the system: flagged per proof by the device's
+            # a.b = c check; the other lanes are unaffected
+            if batch >= 63:
+                bad = batch - 2
+                Wb = W.copy()
+                Wb[bad, cc.n_public + 1, 0] ^= np.uint64(1)       # a secret input wire
+                prover.submit_witness(Wb, rs)
+                p6, s6 = prover.collect()
+                assert list(np.nonzero(s6)[0]) == [bad] and s6[bad] == lib.ZKMI_ERR_UNSATISFIED
+                ok = np.arange(batch) != bad
+                assert np.array_equal(p6[ok], want[ok])
+        with pytest.raises(ValueError):
+            prover.submit_witness(W[:, :-1], rs)
+        with pytest.raises(lib.ZkmiError):     # a, b, c together with the R1CS handle
+            zk_ctx.prove_witness_submit(prover.pk_h, prover.load_r1cs(), W, A, B, Cc,
+                                        cc.n_constraints, W.shape[0], rs)
+    finally:
+        prover.close()
+
+
+def test_r1cs_load_rejects_malformed_matrices(zk_ctx):
+    cc = compile_circuit(circuits.PoseidonCircuit())
+    coeffs = to_mont_array(cc.consts)
+
+    def desc(mut):
+        arrs = []
+        for ptr, col, cid in (cc.L, cc.Rm, cc.O):
+            arrs += [np.ascontiguousarray(ptr, dtype=np.uint32),
+                     np.ascontiguousarray(np.stack([cid, col], axis=1).astype(np.uint32))]
+        c = coeffs.copy()
+        mut(arrs, c)
+        keep = arrs + [c]
+        return lib.R1csDesc(cc.n_wires, cc.n_constraints, len(cc.consts), c.ctypes.data,
+                            *[a.ctypes.data for a in arrs]), keep
+    d, keep = desc(lambda a, c: None)
+    h = zk_ctx.r1cs_load(d)
+    zk_ctx.r1cs_free(h)
+
+    def wire_oob(a, c):
+        a[1][3, 1] = cc.n_wires
+
+    def coeff_oob(a, c):
+        a[3][0, 0] = len(cc.consts)
+
+    def ptr_not_monotone(a, c):
+        a[4][2] = a[4][1] - 1 if a[4][1] else 7
+
+    def coeff_unreduced(a, c):
+        c[0] = H.ints_to_array([H.R])[0]
+    for mut in (wire_oob, coeff_oob, ptr_not_monotone, coeff_unreduced):
+        d, keep = desc(mut)
+        with pytest.raises(lib.ZkmiError):
+            zk_ctx.r1cs_load(d)
+
+
+def test_arbo160_witness_entry_full_size_from_host(zk_ctx):
+    """Arbo-160 x 1024 x 3 batches through zkmi_prove_witness_submit from host buffers under the
+    auto plan (the benched key): wire vectors only (R1CS resident), pipelined; then one batch with
+    W + a + b + c.  A 64-lane sample of every batch equals the C oracle's proofs and every lane
+    equals zkmi_prove_batch on the same inputs."""
+    from oracle import cref
+    B = 1024
+    cc = compile_circuit(circuits.smt_inclusion_circuit(160))
+    pk, vk, td = groth16.setup(cc, 2, groth16.gpu_mul(zk_ctx))
+    prover = groth16.Prover(zk_ctx, cc, pk, 0, 0)
+    info = zk_ctx.pk_info(prover.pk_h)
+    assert info["g1_comb_k"] >= 16 and info["g2_comb_k"] >= 16, info
+    rng = random.Random(777)
+    distinct = 256
+    ws = [to_mont_array(cc.assignment_vector(smt_witness.synthetic_inclusion(rng, 160, 10 + i % 150)))
+          for i in range(distinct)]
+    rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
+    try:
+        batches = []
+        for k in range(3):
+            order = [rng.randrange(distinct) for _ in range(B)]
+            inp = np.stack([ws[i] for i in order])
+            rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in range(B)])
+            # solved witnesses in host memory, as gnark's solver leaves them (here: the GPU solver's
+            # output copied out; the sampled lanes are checked against the oracle's solver below)
+            status, W, abc = prover.solve(inp, want_wires=True, want_abc=(k == 2))
+            assert not status.any()
+            full, fstatus = prover.prove(inp, rs)
+            assert not fstatus.any()
+            batches.append((inp, rs, W, abc, full))
+        for inp, rs, W, abc, full in batches:
+            prover.submit_witness(W, rs)
+            if len(getattr(prover, "_inflight")) == 2:
+                prover._got = getattr(prover, "_got", []) + [prover.collect()]
+        got = getattr(prover, "_got", []) + [prover.collect() for _ in range(len(prover._inflight))]
+        assert len(got) == 3
+        inp, rs, W, abc, full = batches[2]
+        prover.submit_witness(W, rs, abc[0], abc[1], abc[2])
+        got.append(prover.collect())
+        batches.append(batches[2])
+        for k, ((inp, rs, W, abc, full), (proofs, status)) in enumerate(zip(batches, got)):
+            assert not status.any(), k
+            assert np.array_equal(proofs, full), k
+            sample = sorted(set([0, 1, 63, 64, 65, 511, 512, 1022, 1023] +
+                                [rng.randrange(B) for _ in range(64)]))[:64]
+            want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp[sample], rs[sample], 16)
+            assert not wstatus.any()
+            assert np.array_equal(proofs[sample], want), k
+            st1, w1, *_ = cref.r1cs_solve(rh, inp[sample[5]])
+            assert st1 == 0 and np.array_equal(w1, W[sample[5]])
+    finally:
+        prover.close()
