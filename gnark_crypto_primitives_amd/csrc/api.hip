@@ -657,10 +657,13 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
     ctx->err = "pk: log_n out of range [1,28]";
     return ZKMI_ERR_ARG;
   }
-  if (d->n_z + 1 != (1u << d->log_n)) {
-    ctx->err = "pk: n_z must equal 2^log_n - 1";
+  // gnark allocates pk.G1.Z with Domain.Cardinality entries and uses the first n - 1
+  // [UPSTREAM-RECALL]: longer arrays are accepted and truncated
+  if (d->n_z + 1 < (1u << d->log_n)) {
+    ctx->err = "pk: n_z must be at least 2^log_n - 1";
     return ZKMI_ERR_ARG;
   }
+  const uint32_t n_z = (1u << d->log_n) - 1;
   // wire index of every base: explicit arrays, or gnark's InfinityA / InfinityB / nbPublic
   std::vector<uint32_t> wa, wb, wk;
   {
@@ -722,15 +725,15 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   pk->n_a = d->n_a;
   pk->n_b = d->n_b;
   pk->n_k = d->n_k;
-  pk->n_z = d->n_z;
+  pk->n_z = n_z;
   pk->max_batch = d->max_batch ? d->max_batch : 1024;
   int rc;
   // One window plan per group for the whole key.  Auto plans are sized against the free HBM minus
   // the working set of the largest batch the caller will prove (and the caller's own cap).
   const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
-  const size_t n1 = (size_t)d->n_a + d->n_b + d->n_k + d->n_z;
+  const size_t n1 = (size_t)d->n_a + d->n_b + d->n_k + n_z;
   const size_t n_msm_max = std::max(std::max((size_t)d->n_a, (size_t)d->n_b),
-                                    std::max((size_t)d->n_k, (size_t)d->n_z));
+                                    std::max((size_t)d->n_k, (size_t)n_z));
   const size_t n_slots = d->n_slots_hint ? d->n_slots_hint : (size_t)d->n_wires + d->n_wires / 20;
   const double ws = prove_working_set_bytes(d->log_n, n_slots, d->n_wires, pk->max_batch, n_msm_max);
   double usable = free_hbm_bytes() - ws;
@@ -761,7 +764,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   // group (window 0) whatever the group size, so they get small subset-sum tables and the dense
   // quotient MSM (h . Z) gets the HBM: the widest table that fits, sign patterns allowed.
   WinPlan p1z = p1;
-  if (d->sparse_witness >= 2 && auto1 && auto2 && n1 >= 4096 && d->n_z >= 4096) {
+  if (d->sparse_witness >= 2 && auto1 && auto2 && n1 >= 4096 && n_z >= 4096) {
     const int kw = 12;
     const double wire_bytes =
         (double)((d->n_a + kw - 1) / kw + (d->n_b + kw - 1) / kw + (d->n_k + kw - 1) / kw) *
@@ -770,7 +773,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
     if (wire_bytes < 0.5 * usable) {
       int kz = 0, k2 = 0;
       bool sz = true, s2 = true;
-      plan_comb_for_budget(d->n_z, 0, 0.98 * usable - wire_bytes, &kz, &k2, &sz, &s2, true);
+      plan_comb_for_budget(n_z, 0, 0.98 * usable - wire_bytes, &kz, &k2, &sz, &s2, true);
       p1 = plan_comb(kw, false);
       p2 = plan_comb(kw, false);
       p1z = plan_comb(kz, sz);
@@ -791,7 +794,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       (rc = load(1, d->g1_a, d->n_a, p1, auto1, &pk->A)) ||
       (rc = load(1, d->g1_b, d->n_b, p1, auto1, &pk->B1)) ||
       (rc = load(1, d->g1_k, d->n_k, p1, auto1, &pk->K)) ||
-      (rc = load(1, d->g1_z, d->n_z, p1z, auto1, &pk->Z)) ||
+      (rc = load(1, d->g1_z, n_z, p1z, auto1, &pk->Z)) ||
       (rc = load(2, d->g2_b, d->n_b, p2, auto2, &pk->B2))) {
     zkmi_pk_free(ctx, pk);
     return rc;

@@ -10,7 +10,8 @@ Encoding rules restated:
 * field elements are written big-endian, canonical (non-Montgomery) form, 32 bytes;
 * a compressed G1 point is X (32 B) with the two most significant bits of the first byte as flags:
   0b10 = compressed, Y is the lexicographically smallest root; 0b11 = compressed, largest root;
-  0b01 = point at infinity; 0b00 = uncompressed (X || Y, 64 B);
+  0b01 = point at infinity (compressed form); 0b00 = uncompressed (X || Y, 64 B; infinity = 64 zero
+  bytes, and the reader also accepts the 0b01 spelling);
 * a G2 point writes X.A1 then X.A0 (then Y.A1, Y.A0 when uncompressed); "largest" compares A1
   first, then A0;
 * Proof.WriteTo = Ar (compressed) | Bs (compressed) | Krs (compressed) | uint32 number of
@@ -93,7 +94,9 @@ def g1_to_bytes(pt_mont, compressed=True) -> bytes:
     a = np.asarray(pt_mont, dtype=np.uint64).reshape(8)
     size = 32 if compressed else 64
     if not a.any():
-        return bytes([M_INFINITY]) + bytes(size - 1)
+        # raw form: all zero bytes under the "uncompressed" flag (as recalled, gnark-crypto's decoder
+        # consumes only the compressed size on flag 0b01, which would misalign a raw key)
+        return bytes([M_INFINITY]) + bytes(size - 1) if compressed else bytes(size)
     x, y = _fq_plain(a[:4]), _fq_plain(a[4:])
     xb = bytearray(x.to_bytes(32, "big"))
     if not compressed:
@@ -109,6 +112,8 @@ def g1_from_bytes(buf: bytes) -> np.ndarray:
     x = int.from_bytes(bytes([buf[0] & 0x3F]) + buf[1:32], "big")
     if flag == M_UNCOMPRESSED:
         y = int.from_bytes(buf[32:64], "big")
+        if x == 0 and y == 0:                    # raw infinity (both spellings are accepted)
+            return np.zeros(8, dtype=np.uint64)
     else:
         y = _sqrt_fp((x * x * x + 3) % P)
         if y is None:
@@ -123,7 +128,7 @@ def g2_to_bytes(pt_mont, compressed=True) -> bytes:
     a = np.asarray(pt_mont, dtype=np.uint64).reshape(16)
     size = 64 if compressed else 128
     if not a.any():
-        return bytes([M_INFINITY]) + bytes(size - 1)
+        return bytes([M_INFINITY]) + bytes(size - 1) if compressed else bytes(size)
     x0, x1, y0, y1 = (_fq_plain(a[4 * i:4 * i + 4]) for i in range(4))
     xb = bytearray(x1.to_bytes(32, "big") + x0.to_bytes(32, "big"))
     if not compressed:
@@ -140,6 +145,8 @@ def g2_from_bytes(buf: bytes) -> np.ndarray:
     x0 = int.from_bytes(buf[32:64], "big")
     if flag == M_UNCOMPRESSED:
         y1, y0 = int.from_bytes(buf[64:96], "big"), int.from_bytes(buf[96:128], "big")
+        if not (x0 or x1 or y0 or y1):
+            return np.zeros(16, dtype=np.uint64)
     else:
         x = (x0, x1)
         rhs = _f2_mul(_f2_mul(x, x), x)
@@ -293,6 +300,9 @@ def proving_key_from_bytes(buf: bytes, n_public: int):
     pk.a_wire = np.nonzero(maps[0] == 0)[0].astype(np.uint32)
     pk.b_wire = np.nonzero(maps[1] == 0)[0].astype(np.uint32)
     pk.k_wire = np.arange(n_public, n_wires, dtype=np.uint32)
+    # as recalled, gnark allocates G1.Z with Cardinality entries and uses the first n - 1
+    if len(pk.g1_z) >= (1 << pk.log_n) - 1:
+        pk.g1_z = pk.g1_z[:(1 << pk.log_n) - 1]
     if (len(pk.a_wire), len(pk.b_wire), len(pk.k_wire)) != (len(pk.g1_a), len(pk.g1_b), len(pk.g1_k)) \
             or len(pk.g2_b) != len(pk.g1_b) or len(pk.g1_z) != (1 << pk.log_n) - 1:
         raise ValueError("point counts do not match the infinity maps / domain")

@@ -13,7 +13,7 @@ and holds no PLONK vector].
 
 Protocol (DESIGN.md §PLONK): a, b, c blinded by (b1 X + b2) Z_H, z by (b7 X^2 + b8 X + b9) Z_H;
 gamma = H("gamma", vk, public, [a], [b], [c]); beta = H("beta", gamma); alpha = H("alpha", beta,
-[z]); zeta = H("zeta", alpha, [t_lo], [t_mid], [t_hi]); v = H("v", zeta, evaluations); u = H("u",
+[z]); zeta = H("zeta", alpha, [t_lo], [t_mid], [t_hi]); v = H("v", zeta, evaluations); u = H("u", v,
 [W_zeta], [W_zeta_w]).  Quotient chunks hold n + 2 coefficients.
 """
 from __future__ import annotations
@@ -363,13 +363,21 @@ def verify(pk: ProvingKey, public, proof: Proof) -> bool:
     """plonk.Verify: recompute the challenges, assemble the linearisation commitment, one pairing
     check of the two batched KZG openings."""
     com = pk.com
+    # canonical encodings only: challenge() reduces mod r, so an unreduced public input or claimed
+    # evaluation would alias a reduced one
+    if any(not (0 <= int(x) < R) for x in public) or any(not (0 <= int(e) < R) for e in proof.ev):
+        return False
     gamma = challenge("gamma", pk.vk_digest, *public, proof.a, proof.b, proof.c)
     beta = challenge("beta", gamma)
     alpha = challenge("alpha", beta, proof.z)
     zeta = challenge("zeta", alpha, proof.tlo, proof.tmid, proof.thi)
     ev = proof.ev
     v = challenge("v", zeta, *ev)
-    u = challenge("u", proof.wz, proof.wzw)
+    # the folding challenge of the two openings is chained to the whole transcript through v (which
+    # binds zeta, every evaluation and, through zeta / alpha / beta / gamma, all nine commitments and
+    # the public inputs) -- as gnark derives its KZG folding randomness from digests, points and
+    # claimed values; a u that depended on [W_zeta], [W_zeta_w] alone could be fixed in advance
+    u = challenge("u", v, proof.wz, proof.wzw)
     sc = lin_scalars(pk, public, beta, gamma, alpha, zeta, ev)
     w = root_of_unity(pk.log_n)
     add, mul, neg = _verify._g1_add, _verify._g1_mul, _verify._g1_neg

@@ -30,3 +30,17 @@ def synthetic_inclusion(rng, levels, populated, key_bits=None, value_bits=64):
     value = rng.getrandbits(value_bits)
     sib = [rng.randrange(1, R) for _ in range(populated)] + [0] * (levels - populated)
     return {"Root": root_from_path(key, value, sib), "Key": key, "Value": value, "Siblings": sib}
+
+
+def synthetic_exclusion_empty(rng, levels, populated, hasher=poseidon_native.hash):
+    """Exclusion proof against an EMPTY branch (tree/smt/verifier.go:66-81 with isOld0 = 1): the
+    path of ``Key`` ends in the zero leaf after ``populated`` non-zero siblings, the root is the
+    fold of that zero leaf.  Shape of an smt.Verifier assignment."""
+    if not 1 <= populated < levels:
+        raise ValueError("need 1 <= populated < levels")
+    key = rng.getrandbits(levels)
+    sib = [rng.randrange(1, R) for _ in range(populated)] + [0] * (levels - populated)
+    cur = 0
+    for i in range(populated - 1, -1, -1):
+        cur = hasher([sib[i], cur]) if (key >> i) & 1 else hasher([cur, sib[i]])
+    return dict(Root=cur, OldKey=0, OldValue=0, IsOld0=1, Key=key, Value=0, Fnc=1, Siblings=sib)

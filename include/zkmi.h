@@ -75,8 +75,14 @@ int zkmi_h_batch(zkmi_ctx* ctx, const void* a, const void* b, const void* c, voi
  *   100 + c (c in 4..16): that layout with an explicit width;
  *   c in 2..16: the per-window layout (a table d*2^(c*j)*P for every window j, one accumulator);
  *   200 + k (k in 2..20): comb tables -- one joint table of all subset sums per group of k bases,
- *                    254 one-bit windows (254 / k additions per base and proof).  Auto picks the
- *                    layout with the fewest additions that fits. */
+ *                    254 one-bit windows (254 / k additions per base and proof);
+ *   300 + k (k in 3..21): sign-pattern comb tables -- every scalar rewritten as a sum of 254 signed
+ *                    powers of two, one entry P_(k-1) + sum_{i<k-1} +-P_i per sign pattern
+ *                    (2^(k-1) entries serve k bases: one more base per group than 200 + k in the
+ *                    same HBM, but no digit is ever "nothing to add"), 255 windows (254 + a parity
+ *                    correction).  The auto plan's choice for dense witnesses (the Arbo-160 key:
+ *                    319 for G1).
+ *   Auto picks the layout with the fewest additions that fits. */
 typedef struct zkmi_msm_bases zkmi_msm_bases;
 int zkmi_msm_bases_load(zkmi_ctx* ctx, int group, const void* bases, size_t n, int window_bits,
                         zkmi_msm_bases** out);
@@ -110,7 +116,7 @@ typedef struct {
   const void* g1_a;
   const void* g1_b;
   const void* g1_k;
-  const void* g1_z; /* n_z = 2^log_n - 1 */
+  const void* g1_z; /* n_z >= 2^log_n - 1 points; the first 2^log_n - 1 are used */
   const void* g2_b;
   const void* g1_alpha;
   const void* g1_beta;

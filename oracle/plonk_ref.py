@@ -316,13 +316,19 @@ def lin_scalars(key, public, beta, gamma, alpha, zeta, ev):
 # ---- verifier ----------------------------------------------------------------------------------------------
 def verify(key, public, proof):
     com = key["com"]
+    if any(not (0 <= int(x) < R) for x in public) or any(not (0 <= int(e) < R) for e in proof["ev"]):
+        return False
     gamma = challenge("gamma", vk_digest(key), *public, proof["a"], proof["b"], proof["c"])
     beta = challenge("beta", gamma)
     alpha = challenge("alpha", beta, proof["z"])
     zeta = challenge("zeta", alpha, proof["tlo"], proof["tmid"], proof["thi"])
     ev = proof["ev"]
     v = challenge("v", zeta, *ev)
-    u = challenge("u", proof["wz"], proof["wzw"])
+    # the folding challenge of the two openings is chained to the whole transcript through v (which
+    # binds zeta, every evaluation and, through zeta / alpha / beta / gamma, all nine commitments and
+    # the public inputs) -- as gnark derives its KZG folding randomness from digests, points and
+    # claimed values; a u that depended on [W_zeta], [W_zeta_w] alone could be fixed in advance
+    u = challenge("u", v, proof["wz"], proof["wzw"])
     sc = lin_scalars(key, public, beta, gamma, alpha, zeta, ev)
     w = root(key["log_n"])
     add, mul, neg = pyref.g1_add, pyref.g1_mul, pyref.g1_neg
