@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--table-budget-gb", type=float, default=0.0,
                     help="zkmi_pk_desc.table_budget_bytes: cap for the key's MSM tables (0 = "
                          "whatever the free HBM allows); the bounded-memory operating points")
+    ap.add_argument("--bounded-gb", type=float, default=64.0,
+                    help="after the headline: reload the key with this table budget and time "
+                         "--bounded-steps steps (the bounded-memory operating point; 0 = skip)")
+    ap.add_argument("--bounded-steps", type=int, default=8)
     ap.add_argument("--no-cache", action="store_true",
                     help="recompute the compiled circuit and the witnesses instead of using the "
                          "start-up cache ($ZKMI_CACHE_DIR, default $TMPDIR/zkmi-cache-<uid>)")
@@ -613,6 +617,24 @@ def main():
         worst = {"value": global_batch * wc_steps / e_w, "steps": wc_steps,
                  "populated": args.levels - 1, "ms_per_step": e_w / wc_steps * 1e3,
                  "msm_g1_kernel_only_ms": st_w[6] / wc_steps, "unsatisfied": bad_w}
+    # bounded-memory operating point: the same key with its MSM tables capped (a GPU shared with
+    # other circuits); N = 1, headline workload and entry only
+    bounded = None
+    main_info = ctx.pk_info(prover.pk_h)
+    if args.bounded_gb > 0 and world == 1 and B and wit is None and not args.no_pipeline and \
+            args.table_budget_gb == 0 and args.window_g1 == 0 and args.window_g2 == 0:
+        prover.close()
+        prover = groth16.Prover(ctx, cc, pk, 0, 0, max_batch=max(B, 64),
+                                table_budget_bytes=int(args.bounded_gb * 1e9))
+        info_b = ctx.pk_info(prover.pk_h)
+        prover.prove(inp_d, rs_d, proofs_d, status_d)
+        e_b, _ = timed_steps(args.bounded_steps, inp_d, rs_d)
+        same = bool(np.array_equal(proofs_d.cpu().numpy().view(np.uint64), proofs))
+        bounded = {"table_budget_gb": args.bounded_gb, "value": B * args.bounded_steps / e_b,
+                   "steps": args.bounded_steps,
+                   "table_bytes": info_b["g1_table_bytes"] + info_b["g2_table_bytes"],
+                   "g1_comb_k": info_b["g1_comb_k"], "g2_comb_k": info_b["g2_comb_k"],
+                   "proofs_equal_unbounded_run": same}
     if rank == 0:
         stage /= max(args.steps, 1)
         # ---- roofline of the dominant kernel: the G1 accumulate kernel, four launches per step
@@ -624,7 +646,7 @@ def main():
         achieved = alg_bytes / msm_s / 1e9 if msm_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE +
         # WRITE_SIZE of the four launches, raw counter values; same circuit, batch and windows)
-        info = ctx.pk_info(prover.pk_h)
+        info = main_info
         traffic, traffic_source = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
@@ -695,7 +717,7 @@ def main():
                        "constraints": cc.n_constraints, "wires": cc.n_wires,
                        "domain_log2": pk.log_n, "batch_per_gpu": B,
                        "msm_terms_per_proof": {"g1": int(sum(ns)), "g2": ns[1]},
-                       "msm_window_tables": ctx.pk_info(prover.pk_h),
+                       "msm_window_tables": main_info,
                        "global_batch": global_batch,
                        "parallelism": (f"batch-split x{world} ({args.scaling} scaling), "
                                        f"{args.dist_backend if pg else 'no'} process group "
@@ -705,6 +727,7 @@ def main():
             "gathered_on_every_rank": gather_ok,
             "value_worst_case": worst["value"] if worst else None,
             "worst_case": worst,
+            "bounded": bounded,
             "pipelined": not args.no_pipeline,
             "entry": {"inputs": "zkmi_prove_submit (circuit inputs resident in HBM)",
                       "witness": "zkmi_prove_witness_submit, wire vectors from host memory, "
