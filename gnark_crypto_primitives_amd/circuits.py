@@ -114,8 +114,17 @@ class AddressCircuit:
     X = Secret(4)
     Y = Secret(4)
 
+    commit = False
+
     def define(self, api):
         from .ecc.secp256k1 import DeriveAddress, PublicKey
         from .std.emulated import Element
-        addr = DeriveAddress(api, PublicKey(Element(self.X), Element(self.Y)))
+        addr = DeriveAddress(api, PublicKey(Element(self.X), Element(self.Y)), self.commit)
         api.AssertIsEqual(self.Address, addr)
+
+
+class AddressCircuitCommit(AddressCircuit):
+    """The same circuit with the bytes of X and Y range-checked as gnark's ``uints.New`` does it for
+    an R1CS builder: log-derivative lookup + Groth16 commitment (std/rangecheck.py).  A proof of it
+    carries one Pedersen commitment and its proof of knowledge."""
+    commit = True

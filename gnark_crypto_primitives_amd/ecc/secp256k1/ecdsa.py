@@ -13,9 +13,11 @@ class PublicKey:
         self.X, self.Y = X, Y
 
 
-def DeriveAddress(api, pub_key):
-    x_bytes = utils.ElemToU8(api, pub_key.X)
-    y_bytes = utils.ElemToU8(api, pub_key.Y)
+def DeriveAddress(api, pub_key, commit=False):
+    """commit: byte range checks through gnark's commitment-based checker (what ``uints.New`` gives
+    an R1CS builder) instead of boolean wires."""
+    x_bytes = utils.ElemToU8(api, pub_key.X, commit)
+    y_bytes = utils.ElemToU8(api, pub_key.Y, commit)
     pub_bytes = utils.SwapEndianness(x_bytes) + utils.SwapEndianness(y_bytes)
     keccak = sha3.NewLegacyKeccak256(api)
     keccak.Write(pub_bytes)

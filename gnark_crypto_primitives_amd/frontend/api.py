@@ -29,8 +29,16 @@ R = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SETC, OP_ABC, \
     OP_COPY, OP_DIV, OP_BATCHINV, OP_PAIR, OP_MULABC, OP_XORABC, OP_XOR = range(18)
 # OP_XOR: OP_XORABC without its R1CS row (the PLONK lowering emits its own gate rows, scs.py)
+# 18, 19 = OP_FMAC, OP_FMA (relin.py).  Units with operand rows (like OP_BATCHINV + OP_PAIR):
+#   (OP_HIST, first value, n queries, table size) + n x (OP_HQ, 0, query value, 0): multiplicities
+#     m_j = #{queries equal to j}, j < table size, into the consecutive wires first .. first + size - 1
+#   (OP_COMMIT, challenge value, n operands, commitment index) + n x (OP_HQ, 0, value, 0): the
+#     solver stops here; the host commits to the operand wires (Pedersen MSM), hashes and writes the
+#     challenge into the value's slot, then the program continues
+# OP_BITS with b = count | width << 16: `count` limbs of `width` bits each (width 0 / 1: bits).
+OP_HIST, OP_HQ, OP_COMMIT = 20, 21, 22
 
-HINT_INVZERO, HINT_NBITS = 1, 2
+HINT_INVZERO, HINT_NBITS, HINT_LIMBS, HINT_COUNT, HINT_COMMIT = 1, 2, 3, 4, 5
 FIELD_BITS = 254      # bit length of r
 
 
@@ -93,6 +101,8 @@ class API:
         self.val_wire[self.val_one] = 0
         self.val_zero = None
         self.println_log = []
+        self.commitments = []       # {"private": [wires], "hashed": [wires], "wire": w}
+        self._deferred = []
 
     # ------------------------------------------------------------------ plumbing
     def _new_val(self):
@@ -470,6 +480,89 @@ class API:
             self.AssertIsBoolean(b)
             acc = self.Add(acc, self._mul2(b, pow(2, i, R)))
         return acc
+
+    # ------------------------------------------------------------------ hints and commitments
+    def Defer(self, fn):
+        """frontend.Compiler.Defer: fn(api) runs after the circuit's Define (the range checker and
+        the multi-commitment build their arguments there)."""
+        self._deferred.append(fn)
+
+    def finalize(self):
+        while self._deferred:
+            self._deferred.pop(0)(self)
+
+    def _single_wire(self, v):
+        """wire index of a variable that is exactly one wire (coefficient 1); any other expression
+        gets a fresh internal wire equal to it (one constraint), as gnark's Commit does."""
+        if len(v.lc) == 1:
+            (w, c), = v.lc.items()
+            if c == 1 and w != 0:
+                return w, v
+        val = self._emit(OP_COPY, v.val)
+        res, w = self._internal(val)
+        self._add_r1c(self._const(1), v, res, solve_wire=w)
+        return w, res
+
+    def NewHintLimbs(self, a, width, count):
+        """Unconstrained hint (std/rangecheck DecomposeHint, uints toBytes): ``count`` limbs of
+        ``width`` bits of a, least significant first, as fresh internal wires."""
+        a = self._v(a)
+        if not 1 <= width <= 16 or not 1 <= count <= 256 or width * count > 256:
+            raise CompileError("limb hint: width in [1,16], width * count <= 256")
+        first = self._new_val()
+        vals = [first] + [self._new_val() for _ in range(count - 1)]
+        self.ops.append((OP_BITS, first, a.val, count | width << 16))
+        wires = [self._new_wire(v) for v in vals]
+        self.hints.append((HINT_LIMBS, [{0: width}, a.lc], wires))
+        self.instr.append((1, len(self.hints) - 1))
+        return [Variable({w: 1}, v) for w, v in zip(wires, vals)]
+
+    def NewHintCount(self, queries, table_size):
+        """Unconstrained hint (std/lookup/logderivarg countHint for the table 0 .. size - 1):
+        multiplicity of every table entry among the queries, as fresh internal wires."""
+        qs = [self._v(q) for q in queries]
+        first = self._new_val()
+        vals = [first] + [self._new_val() for _ in range(table_size - 1)]
+        self.ops.append((OP_HIST, first, len(qs), table_size))
+        for q in qs:
+            self.ops.append((OP_HQ, 0, q.val, 0))
+        wires = [self._new_wire(v) for v in vals]
+        self.hints.append((HINT_COUNT, [{0: table_size}] + [q.lc for q in qs], wires))
+        self.instr.append((1, len(self.hints) - 1))
+        return [Variable({w: 1}, v) for w, v in zip(wires, vals)]
+
+    def Commit(self, *vs):
+        """frontend.Committer.Commit (gnark r1cs builder, Groth16 commitment extension
+        [UPSTREAM-RECALL, SURVEY.md §3.2 step 6]): returns a wire holding
+        H(Pedersen commitment to the private operands || public operands).  Constants are dropped;
+        public wires and earlier commitment wires are hashed, every other operand is a basis point
+        of the commitment key.  The solver cannot produce the value itself: the program stops at an
+        OP_COMMIT unit and the prover supplies it (csrc/commit.hip)."""
+        self._inputs_open = False
+        priv, hashed, seen, reads = [], [], set(), []
+        cwires = {c["wire"] for c in self.commitments}
+        for x in vs:
+            x = self._v(x)
+            if x.is_const():
+                continue
+            w, x = self._single_wire(x)
+            if w in seen:
+                continue
+            seen.add(w)
+            (hashed if (w < self.n_public or w in cwires) else priv).append(w)
+            reads.append(x.val)
+        if not priv and not hashed:
+            raise CompileError("Commit: nothing to commit to")
+        val = self._new_val()
+        res, w = self._internal(val)
+        idx = len(self.commitments)
+        self.ops.append((OP_COMMIT, val, len(reads), idx))
+        for r in reads:
+            self.ops.append((OP_HQ, 0, r, 0))
+        self.commitments.append({"private": priv, "hashed": hashed, "wire": w})
+        self.hints.append((HINT_COMMIT, [{0: len(hashed)}] + [{x: 1} for x in hashed + priv], [w]))
+        self.instr.append((1, len(self.hints) - 1))
+        return res
 
     # ------------------------------------------------------------------ assertions
     def AssertIsEqual(self, a, b):

@@ -14,8 +14,8 @@ import hashlib
 import numpy as np
 
 from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS,
-                  OP_COPY, OP_DIV, OP_END, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR,
-                  OP_SETC, OP_XOR, OP_XORABC,
+                  OP_COMMIT, OP_COPY, OP_DIV, OP_END, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC,
+                  OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_XOR, OP_XORABC,
                   OP_SUB, R)
 
 
@@ -84,7 +84,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     BATCHINV step is followed by ceil(n / S) rows of (OP_PAIR, dst, src) quads.  Temporaries are
     recycled by step."""
     from . import schedule as sch
-    bits_vals = {o[1]: range(o[1], o[1] + o[3]) for o in ops if o[0] == OP_BITS}
+    bits_vals = {o[1]: range(o[1], o[1] + (o[3] & 0xffff)) for o in ops if o[0] == OP_BITS}
     best = None
     # auto: 4 sub-lanes (idle sub-lanes cost nothing: the solve is a latency chain on an
     # otherwise empty SIMD), more only while doubling them shortens the schedule by >= 8 %
@@ -104,8 +104,8 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     for t, (c, idxs) in enumerate(steps):
         for i in idxs:
             op, dst, a, b = ops[i][:4]
-            if op == OP_BATCHINV:
-                for q in range(1, dst + 1):
+            if op in (OP_BATCHINV, OP_HIST, OP_COMMIT):
+                for q in range(1, sch.n_rows_of(ops[i]) + 1):
                     last[ops[i + q][2]] = t
             else:
                 for v in sch.reads_of(*ops[i]):
@@ -140,7 +140,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         # destinations first get their slots (sources are all older values)
         for i in idxs:
             op, dst, a, b = ops[i][:4]
-            if op in (OP_ABC, OP_BATCHINV, OP_BITS):
+            if op in (OP_ABC, OP_BATCHINV, OP_BITS, OP_HIST, OP_COMMIT):
                 continue
             if dst not in slot:
                 if free:
@@ -162,14 +162,34 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
                 chunk = pairs[r * S:(r + 1) * S]
                 rows.append([(sch.CLS_BINV | 0x100, len(chunk), 0, 0)] + chunk +
                             [(0, 0, 0, 0)] * (S - len(chunk)))
+        elif c in (sch.CLS_HIST, sch.CLS_COMMIT):
+            # class field of the quads = 0: the kernel takes the class from the header quad.
+            # HIST: header (class, n queries, n rows, table size), quad 0 = (OP_HIST, first slot);
+            # then ceil(n / S) rows of (OP_HQ, 0, query slot, 0).  COMMIT: one row, header (class,
+            # n operands, 0, commitment index), quad 0 = (OP_COMMIT, challenge slot, 0, index): the
+            # host ends a kernel launch in front of it (zkmi_cs_load records the row).
+            i = idxs[0]
+            op, dst, n_q, aux = ops[i][:4]
+            if c == sch.CLS_HIST:
+                nrows = -(-n_q // S)
+                rows.append([(c, n_q, nrows, aux), (OP_HIST, slot[dst], 0, aux)] +
+                            [(0, 0, 0, 0)] * (S - 1))
+                qs = [(OP_HQ, 0, slot[ops[i + q][2]], 0) for q in range(1, n_q + 1)]
+                for r in range(nrows):
+                    chunk = qs[r * S:(r + 1) * S]
+                    rows.append([(c | 0x100, len(chunk), 0, 0)] + chunk +
+                                [(0, 0, 0, 0)] * (S - len(chunk)))
+            else:
+                rows.append([(c, n_q, 0, aux), (OP_COMMIT, slot[dst], 0, aux)] +
+                            [(0, 0, 0, 0)] * (S - 1))
         else:
             quads = [quad(i, c) for i in idxs]
             rows.append([hdr] + quads + [(c << 6, 0, 0, 0)] * (S - len(quads)))
         # temporaries whose last reader is this step return to the pool for LATER steps
         for i in idxs:
             op, dst, a, b = ops[i][:4]
-            srcs = [ops[i + q][2] for q in range(1, dst + 1)] if op == OP_BATCHINV \
-                else sch.reads_of(*ops[i])
+            srcs = [ops[i + q][2] for q in range(1, sch.n_rows_of(ops[i]) + 1)] \
+                if op in (OP_BATCHINV, OP_HIST, OP_COMMIT) else sch.reads_of(*ops[i])
             for v in set(srcs):
                 if last.get(v) == t and v not in val_wire and v in slot:
                     released.append(slot.pop(v))
@@ -207,6 +227,11 @@ class CompiledCircuit:
         self.constraints = api.constraints
         self.instr = np.array(api.instr, dtype=np.uint32).reshape(-1, 2)
         self.hints = api.hints
+        # Groth16 commitment extension (gnark constraint.Groth16Commitments): per commitment the
+        # private committed wires (basis order), the hashed public / commitment wires and the wire
+        # that receives the challenge
+        self.commitments = [dict(c) for c in api.commitments]
+        self.commit_fn = None      # run_program / run_vprogram: (index, hashed, committed) -> int
         self._build_csr(api)
         self._build_program(api)
 
@@ -264,6 +289,11 @@ class CompiledCircuit:
             elif op == OP_BITS:
                 keep[i] = True
                 live[a] = True
+            elif op in (OP_HIST, OP_COMMIT):
+                keep[i] = True
+            elif op == OP_HQ:
+                keep[i] = True
+                live[a] = True
             elif live[dst]:
                 keep[i] = True
                 if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
@@ -288,7 +318,7 @@ class CompiledCircuit:
                 last[dst] = last[a] = last[b] = i
             elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC):
                 last[a] = last[b] = i
-            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS, OP_PAIR):
+            elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS, OP_PAIR, OP_HQ):
                 last[a] = i
         # ---- slot assignment: wire-backed values live in their wire's slot forever; the rest
         # share a pool of temporaries above n_wires, recycled after the last use
@@ -303,6 +333,14 @@ class CompiledCircuit:
                 continue
             if op == OP_PAIR:
                 prog[i] = (op, slot[dst], slot[a], 0)   # both wire-backed, never recycled
+                continue
+            if op in (OP_HIST, OP_COMMIT):
+                prog[i] = (op, slot[dst], a, b)         # dst wire-backed; a operand rows follow
+                continue
+            if op == OP_HQ:
+                prog[i] = (op, 0, slot[a], 0)
+                if last.get(a) == i and a not in val_wire:
+                    free.append(slot[a])
                 continue
             if op == OP_ABC:
                 srcs = (dst, a, b)
@@ -387,6 +425,19 @@ class CompiledCircuit:
                             s[d] = pow(s[x], R - 2, R)
                     r += 1
                 continue
+            if cls == sch.CLS_HIST:
+                first, size = quads[0][1], hdr[3]
+                for j in range(size):
+                    s[first + j] = 0
+                for _ in range(hdr[2]):
+                    for w0, d, x, _y in rows[r][1:]:
+                        if w0 & 0x1f == OP_HQ and s[x] < size:
+                            s[first + s[x]] += 1
+                    r += 1
+                continue
+            if cls == sch.CLS_COMMIT:
+                s[quads[0][1]] = self._commit_value(hdr[3], s)
+                continue
             writes = []
             for w0, d, x, y in quads:
                 op, chk, k = w0 & 0x1f, (w0 >> 5) & 1, w0 >> 9
@@ -431,9 +482,9 @@ class CompiledCircuit:
                     if chk and s[d] * s[x] % R != s[y]:
                         self.last_status = -5
                 elif op == OP_BITS:
-                    v = s[x]
-                    for j in range(y):
-                        writes.append((d + j, (v >> j) & 1))
+                    v, width = s[x], (y >> 16) or 1
+                    for j in range(y & 0xffff):
+                        writes.append((d + j, (v >> (j * width)) & ((1 << width) - 1)))
                 else:
                     raise AssertionError(op)
             for d, v in writes:
@@ -453,8 +504,11 @@ class CompiledCircuit:
         a_, b_, c_ = [], [], []
         C = self.consts
         self.last_status = 0
+        hist = None
         for op, d, a, b in self.program.tolist():
             chk, op = op & 0x100, op & 0xff
+            if op not in (OP_HQ, OP_HIST):
+                hist = None
             if op == OP_MUL:
                 s[d] = s[a] * s[b] % R
             elif op == OP_ADD:
@@ -491,9 +545,19 @@ class CompiledCircuit:
             elif op == OP_DIV:
                 s[d] = s[a] * pow(s[b], R - 2, R) % R
             elif op == OP_BITS:
-                v = s[a]
+                v, width = s[a], (b >> 16) or 1
+                for k in range(b & 0xffff):
+                    s[d + k] = (v >> (k * width)) & ((1 << width) - 1)
+            elif op == OP_HIST:
+                hist = (d, b)
                 for k in range(b):
-                    s[d + k] = (v >> k) & 1
+                    s[d + k] = 0
+            elif op == OP_HQ:
+                if hist is not None and s[a] < hist[1]:     # rows of an OP_COMMIT only order it
+                    s[hist[0] + s[a]] += 1
+            elif op == OP_COMMIT:
+                hist = None
+                s[d] = self._commit_value(b, s)
             elif op == OP_COPY:
                 s[d] = s[a]
             elif op == OP_PAIR:                      # row of a preceding OP_BATCHINV
@@ -501,6 +565,21 @@ class CompiledCircuit:
             elif op == OP_END:
                 break
         return s[:self.n_wires], a_, b_, c_
+
+    def _commit_value(self, idx, s):
+        """challenge of commitment ``idx`` from the current slot values: ``commit_fn(idx, hashed
+        values, committed values)`` -- groth16.commit_fn(pk) is the real one (Pedersen MSM +
+        hash-to-field); without one a SHA-256 stand-in keeps the CPU interpreters self-contained
+        (the circuit logic does not depend on where the challenge comes from)."""
+        c = self.commitments[idx]
+        hashed = [s[w] for w in c["hashed"]]
+        committed = [s[w] for w in c["private"]]
+        if self.commit_fn is not None:
+            return int(self.commit_fn(idx, hashed, committed)) % R
+        h = hashlib.sha256(b"stand-in commitment %d" % idx)
+        for v in hashed + committed:
+            h.update(int(v).to_bytes(32, "big"))
+        return int.from_bytes(h.digest(), "big") % R
 
     def is_satisfied(self, wires):
         """Check every constraint <L,w>*<R,w> == <O,w> on a full wire assignment."""
@@ -556,4 +635,5 @@ def compile_circuit(circuit, lanes_per_proof: int = 0, relinearize: bool = True)
                 setattr(circuit, name, [mk(f"{name}[{i}]") for i in range(f.n)])
             layout.append((name, f.n, want_public))
     circuit.define(api)
+    api.finalize()                    # deferred builders: range checker, multi-commitment
     return CompiledCircuit(api, layout, lanes_per_proof, relinearize)

@@ -24,8 +24,9 @@ rewritten, scheduled program against the sequential one.
 """
 from __future__ import annotations
 
-from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COPY, OP_DIV, OP_INV, OP_MUL,
-                  OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR, OP_XORABC, R)
+from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COMMIT, OP_COPY, OP_DIV, OP_HIST,
+                  OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR,
+                  OP_XORABC, R)
 
 OP_FMAC, OP_FMA = 18, 19          # (op, dst, x, const index, addend)  /  (op, dst, x, y, addend)
 LINEAR = (OP_ADD, OP_SUB, OP_ADDC, OP_MULC, OP_NEG, OP_COPY, OP_SETC)
@@ -170,13 +171,23 @@ def relinearize(ops, val_wire, consts, n_vals):
                 out.append(o)                        # (OP_PAIR, dst wire, src wire): inputs only
                 depth[o[1]] = 4000
             continue
+        if op in (OP_HIST, OP_COMMIT):
+            # operand rows: materialised values; the unit defines wire-backed values only
+            rows = [use(ops[i + j][2]) for j in range(a)]
+            i += a
+            out.append((op, dst, a, b))
+            out.extend((OP_HQ, 0, x, 0) for x in rows)
+            d = max([dep(x) for x in rows], default=0) + (4000 if op == OP_HIST else 20000)
+            for v in (range(dst, dst + b) if op == OP_HIST else (dst,)):
+                depth[v] = d
+            continue
         if op == OP_ABC:
             out.append((op, use(dst), use(a), use(b)))
             continue
         if op == OP_BITS:
             xa = use(a)
             out.append((op, dst, xa, b))
-            for v in range(dst, dst + b):
+            for v in range(dst, dst + (b & 0xffff)):
                 depth[v] = dep(xa) + 40
             continue
         if op in (OP_INV,):

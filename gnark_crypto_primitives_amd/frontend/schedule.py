@@ -15,23 +15,41 @@ Classes (one opcode switch per step on the GPU; sub-lanes differ only in operand
   R  rows             OP_ABC
   I  inversions       OP_INV, OP_DIV
   BITS, BATCHINV      one instruction per step; the sub-lanes split its bits / its pairs
+  HIST                one instruction per step: multiplicities of a lookup table (sub-lane 0 counts)
+  COMMIT              one instruction per step: the solver stops, the prover commits (csrc/commit.hip)
 List scheduling by longest path to a sink (class costs ~ instruction counts of the kernel).
 """
 from __future__ import annotations
 
 import heapq
 
-from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COPY, OP_DIV, OP_INV, OP_MUL,
-                  OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR, OP_XORABC)
+from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COMMIT, OP_COPY, OP_DIV, OP_HIST,
+                  OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR,
+                  OP_XORABC)
 
 OP_FMAC, OP_FMA = 18, 19       # relin.py: (op, dst, x, const, addend) / (op, dst, x, y, addend)
-CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV = range(1, 8)
+CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT = range(1, 10)
+# the class field of an operand quad has three bits: HIST / COMMIT rows carry 0 there and their
+# class in the header quad
+SINGLE = (CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT)
 CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_FMA: CLS_M, OP_XORABC: CLS_X, OP_XOR: CLS_X,
             OP_ADD: CLS_A, OP_SUB: CLS_A, OP_ADDC: CLS_A, OP_NEG: CLS_A, OP_COPY: CLS_A,
             OP_SETC: CLS_A, OP_ABC: CLS_R, OP_INV: CLS_I, OP_DIV: CLS_I, OP_BITS: CLS_BITS,
-            OP_BATCHINV: CLS_BINV}
+            OP_BATCHINV: CLS_BINV, OP_HIST: CLS_HIST, OP_COMMIT: CLS_COMMIT}
 # relative time of one step of the class on a lone wavefront (instruction counts / 40)
-COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000}
+COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000,
+        CLS_HIST: 4000, CLS_COMMIT: 20000}
+
+
+def n_rows_of(o):
+    """operand rows that follow a unit op (OP_PAIR rows of OP_BATCHINV, OP_HQ rows of OP_HIST /
+    OP_COMMIT)"""
+    return o[1] if o[0] == OP_BATCHINV else o[2] if o[0] in (OP_HIST, OP_COMMIT) else 0
+
+
+def bits_count(b):
+    """values an OP_BITS with operand b defines (b = count | width << 16)"""
+    return b & 0xffff
 
 
 def reads_of(op, dst, a, b, z=None):
@@ -65,6 +83,11 @@ def schedule(ops, n_bits_vals, S):
                 producer[ops[i + k][1]] = i
             i += dst + 1
             continue
+        if op in (OP_HIST, OP_COMMIT):
+            for v in (range(dst, dst + b) if op == OP_HIST else (dst,)):
+                producer[v] = i
+            i += a + 1
+            continue
         if op == OP_BITS:
             for v in n_bits_vals[dst]:
                 producer[v] = i
@@ -75,8 +98,8 @@ def schedule(ops, n_bits_vals, S):
     npred = {u: 0 for u in units}
     for u in units:
         op, dst, a, b = ops[u][:4]
-        if op == OP_BATCHINV:
-            rd = [ops[u + k][2] for k in range(1, dst + 1)]
+        if op in (OP_BATCHINV, OP_HIST, OP_COMMIT):
+            rd = [ops[u + k][2] for k in range(1, n_rows_of(ops[u]) + 1)]
         else:
             rd = reads_of(*ops[u])
         seen = set()
@@ -107,7 +130,7 @@ def schedule(ops, n_bits_vals, S):
         for c, h in ready.items():
             if h and (best_p is None or h[0][0] < best_p):
                 best_c, best_p = c, h[0][0]
-        cap = 1 if best_c in (CLS_BITS, CLS_BINV) else S
+        cap = 1 if best_c in SINGLE else S
         chosen = []
         h = ready[best_c]
         while h and len(chosen) < cap:

@@ -1,10 +1,13 @@
 """Byte and 64-bit word values inside a circuit: what the reference takes from gnark's
 ``std/math/uints`` (U8, ``uints.New[uints.U64]`` / ``BinaryField.ValueOf``, utils/uints.go:14-28).
 
-gnark range-checks bytes with a log-derivative lookup argument backed by a commitment; this build's
-Groth16 path has no commitment extension, so a byte is pinned by its eight boolean wires instead.
-The gadget-level meaning is the same: ``ValueOf(v)`` constrains v < 2^64 and returns its eight
-bytes little-endian; every U8 is constrained to [0, 256).
+gnark range-checks bytes with a log-derivative lookup argument backed by a commitment
+(``uints.New`` -> ``rangecheck.New``).  ``BinaryField(api, commit=True)`` does the same: ``ValueOf``
+takes the bytes from a hint, asserts the recomposition and hands every byte to the commitment-based
+range checker (std/rangecheck.py).  The default (``commit=False``) pins a byte by its eight boolean
+wires instead -- cheaper for this repo's boolean Keccak, which needs the bits anyway, and free of the
+commitment.  The gadget-level meaning is the same either way: ``ValueOf(v)`` constrains v < 2^64 and
+returns its eight bytes little-endian; every U8 is constrained to [0, 256).
 """
 
 
@@ -27,9 +30,13 @@ def NewU8(v):
 
 class BinaryField:
     """uints.BinaryField[U64] (``uints.New[uints.U64](api)``)."""
-    def __init__(self, api, word_bytes=8):
+    def __init__(self, api, word_bytes=8, commit=False):
         self.api = api
         self.word_bytes = word_bytes
+        self.rchecker = None
+        if commit:
+            from . import rangecheck
+            self.rchecker = rangecheck.New(api)
 
     def Bits(self, b):
         """The eight boolean wires of a byte, LSB first (decomposed once, then cached)."""
@@ -43,11 +50,20 @@ class BinaryField:
 
     def ByteValueOf(self, v):
         """uints.BinaryField.ByteValueOf: v as one range-checked byte."""
+        if self.rchecker is not None:
+            self.rchecker.Check(v, 8)
+            return U8(v)
         bits = self.api.ToBinary(v, 8)
         return U8(v, bits)
 
     def ValueOf(self, v):
         """uints.BinaryField.ValueOf: v < 2^(8*word_bytes) as bytes, least significant first."""
+        if self.rchecker is not None:
+            # gnark: bytes from the toBytes hint, each through ByteValueOf, recomposition asserted
+            bts = self.api.NewHintLimbs(v, 8, self.word_bytes)
+            word = [self.ByteValueOf(b) for b in bts]
+            self.api.AssertIsEqual(v, self.ToValue(word))
+            return word
         bits = self.api.ToBinary(v, 8 * self.word_bytes)
         return [self.ByteFromBits(bits[8 * i:8 * i + 8]) for i in range(self.word_bytes)]
 

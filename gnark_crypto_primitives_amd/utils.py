@@ -17,10 +17,11 @@ def PoseidonMultiHasher(api, *data):
 
 
 # ---- utils/uints.go -------------------------------------------------------------------------------
-def ElemToU8(api, elem):
+def ElemToU8(api, elem, commit=False):
     """utils.ElemToU8 (utils/uints.go:14-28): every limb through ``bf.ValueOf`` (eight bytes,
-    least significant first), limbs in order."""
-    bf = BinaryField(api)
+    least significant first), limbs in order.  commit: range-check the bytes the way gnark's
+    ``uints.New`` does, through the commitment-based checker (std/rangecheck.py)."""
+    bf = BinaryField(api, commit=commit)
     res = []
     for limb in elem.Limbs:
         res.extend(bf.ValueOf(limb))
