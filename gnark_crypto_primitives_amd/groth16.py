@@ -62,6 +62,10 @@ class ProvingKey:
         self.a_wire = self.b_wire = self.k_wire = None     # uint32
         self.g1_a = self.g1_b = self.g1_k = self.g1_z = self.g2_b = None
         self.g1_alpha = self.g1_beta = self.g1_delta = self.g2_beta = self.g2_delta = None
+        # gnark ProvingKey.CommitmentKeys (pedersen.ProvingKey {Basis, BasisExpSigma}) plus the wire
+        # lists of constraint.Groth16Commitments: [{"basis", "basis_exp_sigma" (n x 8 uint64),
+        # "private", "hashed" (wire indices), "wire"}]
+        self.commitment_keys = []
 
     def nbytes(self):
         return sum(x.nbytes for x in (self.g1_a, self.g1_b, self.g1_k, self.g1_z, self.g2_b))
@@ -79,7 +83,12 @@ class ProvingKey:
 class VerifyingKey:
     def __init__(self):
         self.g1_alpha = self.g2_beta = self.g2_gamma = self.g2_delta = None
-        self.g1_k = None            # one point per public wire (ONE first)
+        self.g1_k = None            # one point per public wire (ONE first), then one per commitment
+        # gnark VerifyingKey.CommitmentKey (pedersen.VerifyingKey {G, GSigmaNeg}) and
+        # PublicAndCommitmentCommitted (here: wire indices hashed with each commitment)
+        self.commitment_g = self.commitment_g_sigma_neg = None
+        self.commitment_hashed = []
+        self.commitment_wires = []
 
 
 def sample_trapdoor(seed):
@@ -113,7 +122,15 @@ def setup(cc: CompiledCircuit, seed, mul):
     pk.log_n, pk.n_wires = log_n, nw
     a_wire = [i for i in range(nw) if A[i]]
     b_wire = [i for i in range(nw) if B[i]]
-    k_wire = list(range(cc.n_public, nw))
+    # commitment extension (gnark setup.go): private committed wires and commitment wires leave
+    # pk.G1.K; the former become the Pedersen bases (their K scalar over gamma, like a public
+    # wire's), the latter join vk.G1.K after the public wires
+    coms = getattr(cc, "commitments", [])
+    taken = set()
+    for c in coms:
+        taken.update(c["private"])
+        taken.add(c["wire"])
+    k_wire = [i for i in range(cc.n_public, nw) if i not in taken]
     pk.a_wire = np.array(a_wire, dtype=np.uint32)
     pk.b_wire = np.array(b_wire, dtype=np.uint32)
     pk.k_wire = np.array(k_wire, dtype=np.uint32)
@@ -125,7 +142,14 @@ def setup(cc: CompiledCircuit, seed, mul):
         t = t * tau % R
     g1_scalars = ([A[i] for i in a_wire] + [B[i] for i in b_wire] +
                   [kk[i] * dinv % R for i in k_wire] + z +
-                  [kk[i] * ginv % R for i in range(cc.n_public)] + [alpha, beta, delta])
+                  [kk[i] * ginv % R for i in range(cc.n_public)] +
+                  [kk[c["wire"]] * ginv % R for c in coms] + [alpha, beta, delta])
+    if coms:
+        rng = random.Random((int(seed) << 8) ^ 0xC0)
+        sigma, rho = rng.randrange(1, R), rng.randrange(1, R)
+        for c in coms:
+            g1_scalars += [kk[i] * ginv % R for i in c["private"]]
+            g1_scalars += [kk[i] * ginv % R * sigma % R for i in c["private"]]
     g1_pts = mul(1, to_mont_array(g1_scalars))
     o = 0
 
@@ -136,15 +160,42 @@ def setup(cc: CompiledCircuit, seed, mul):
         return r
     pk.g1_a, pk.g1_b, pk.g1_k, pk.g1_z = (take(len(a_wire)), take(len(b_wire)), take(len(k_wire)),
                                           take(n - 1))
-    vk.g1_k = take(cc.n_public)
+    vk.g1_k = take(cc.n_public + len(coms))
     pk.g1_alpha, pk.g1_beta, pk.g1_delta = (take(1).reshape(-1) for _ in range(3))
+    for c in coms:
+        n_p = len(c["private"])
+        pk.commitment_keys.append({"basis": take(n_p), "basis_exp_sigma": take(n_p),
+                                   "private": list(c["private"]), "hashed": list(c["hashed"]),
+                                   "wire": c["wire"]})
+        vk.commitment_hashed.append(list(c["hashed"]))
+        vk.commitment_wires.append(c["wire"])
     vk.g1_alpha = pk.g1_alpha
-    g2_pts = mul(2, to_mont_array([B[i] for i in b_wire] + [beta, delta, gamma]))
+    g2_pts = mul(2, to_mont_array([B[i] for i in b_wire] + [beta, delta, gamma] +
+                                  ([rho, (R - sigma) * rho % R] if coms else [])))
     nb = len(b_wire)
+    if coms:
+        vk.commitment_g, vk.commitment_g_sigma_neg = g2_pts[nb + 3].copy(), g2_pts[nb + 4].copy()
     pk.g2_b = np.ascontiguousarray(g2_pts[:nb])
     pk.g2_beta, pk.g2_delta = g2_pts[nb].copy(), g2_pts[nb + 1].copy()
     vk.g2_beta, vk.g2_delta, vk.g2_gamma = pk.g2_beta, pk.g2_delta, g2_pts[nb + 2].copy()
     return pk, vk, trapdoor
+
+
+def commit_fn(pk: ProvingKey):
+    """Host evaluation of the commitment hint for CompiledCircuit.run_program / run_vprogram (the
+    CPU interpreters of the frontend tests): Pedersen commitment over pk.CommitmentKeys[i].Basis in
+    Python integers, then hash_to_field -- the same value the GPU prover writes into the commitment
+    wire (csrc/commit.hip)."""
+    from . import hash_to_field, verify as _v
+    bases = [[_v.g1_from_image(b) for b in ck["basis"]] for ck in pk.commitment_keys]
+
+    def fn(idx, hashed, committed):
+        acc = None
+        for pt, s in zip(bases[idx], committed):
+            if s % R and pt is not None:
+                acc = _v._g1_add(acc, _v._g1_mul(pt, s % R))
+        return hash_to_field.commitment_challenge(acc, hashed)
+    return fn
 
 
 def gpu_mul(ctx: _lib.Context):

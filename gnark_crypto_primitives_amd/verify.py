@@ -252,19 +252,106 @@ def g2_from_image(a):
     return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
 
 
-def verify(vk, public_inputs, proof) -> bool:
+def _g2_add(a, b):
+    """affine addition on the twist (Fq2 coordinates)"""
+    if a is None or b is None:
+        return a if b is None else b
+    mul2 = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+    sub2 = lambda x, y: ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+
+    def inv2(x):
+        d = pow((x[0] * x[0] + x[1] * x[1]) % P, P - 2, P)
+        return (x[0] * d % P, (-x[1]) * d % P)
+    if a[0] == b[0]:
+        if ((a[1][0] + b[1][0]) % P, (a[1][1] + b[1][1]) % P) == (0, 0):
+            return None
+        x2 = mul2(a[0], a[0])
+        lam = mul2(((3 * x2[0]) % P, (3 * x2[1]) % P), inv2(((2 * a[1][0]) % P, (2 * a[1][1]) % P)))
+    else:
+        lam = mul2(sub2(b[1], a[1]), inv2(sub2(b[0], a[0])))
+    x = sub2(sub2(mul2(lam, lam), a[0]), b[0])
+    return x, sub2(mul2(lam, sub2(a[0], x)), a[1])
+
+
+def _in_g2_subgroup(q):
+    """[r] Q == O.  BN254's twist has a large cofactor: a point on the curve is not necessarily in
+    the order-r subgroup the pairing is defined on (gnark's decoder rejects such points)."""
+    if q is None:
+        return True
+    acc, base, k = None, q, R
+    while k:
+        if k & 1:
+            acc = _g2_add(acc, base)
+        base = _g2_add(base, base)
+        k >>= 1
+    return acc is None
+
+
+def _canonical(words):
+    """every Fq coordinate of a point image is a reduced Montgomery residue"""
+    return all(v < P for v in array_to_ints(np.ascontiguousarray(words).reshape(-1, 4)))
+
+
+def verify(vk, public_inputs, proof, commitments=None, pok=None) -> bool:
     """groth16.Verify.  vk: groth16.VerifyingKey (numpy arrays, gnark's image); public_inputs: the
-    public wire values as integers (without the ONE wire); proof: uint64[32] = Ar | Krs | Bs."""
+    public wire values as integers (without the ONE wire); proof: uint64[32] = Ar | Krs | Bs.
+    Keys with the commitment extension (vk.commitment_wires): ``commitments`` = uint64[n, 8]
+    Pedersen commitments (proof.Commitments), ``pok`` = uint64[8] (proof.CommitmentPok); the
+    commitment wires' values are recomputed by hashing, the folded proof of knowledge is checked
+    with one more pairing product, and the commitments join the public-input sum
+    (gnark backend/groth16/bn254/verify.go [UPSTREAM-RECALL])."""
+    from . import hash_to_field as h2f
     proof = np.ascontiguousarray(proof, dtype=np.uint64).reshape(32)
+    if not _canonical(proof):
+        return False
     ar, krs, bs = g1_from_image(proof[0:8]), g1_from_image(proof[8:16]), g2_from_image(proof[16:32])
     if not (_on_g1(ar) and _on_g1(krs) and _on_g2(bs)) or ar is None or bs is None:
         return False
+    if not _in_g2_subgroup(bs):
+        return False
+    public_inputs = [int(x) for x in public_inputs]
+    if any(not 0 <= x < R for x in public_inputs):
+        return False                 # canonical encodings only: _g1_mul would reduce mod r
     ks = [g1_from_image(k) for k in vk.g1_k]
-    if len(public_inputs) + 1 != len(ks):
-        raise ValueError(f"expected {len(ks) - 1} public inputs, got {len(public_inputs)}")
+    n_com = len(getattr(vk, "commitment_wires", []))
+    if len(public_inputs) + 1 + n_com != len(ks):
+        raise ValueError(f"expected {len(ks) - 1 - n_com} public inputs, got {len(public_inputs)}")
+    extra = []
+    if n_com:
+        if commitments is None or pok is None:
+            return False
+        commitments = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(n_com, 8)
+        pok = np.ascontiguousarray(pok, dtype=np.uint64).reshape(8)
+        if not _canonical(commitments) or not _canonical(pok):
+            return False
+        ds = [g1_from_image(c) for c in commitments]
+        pk_pt = g1_from_image(pok)
+        if not all(_on_g1(d) for d in ds) or not _on_g1(pk_pt):
+            return False
+        # value of every commitment wire: hash of its commitment and of the public / earlier
+        # commitment wires committed with it (wire w < nbPublic: public_inputs[w - 1])
+        n_pub = len(public_inputs) + 1
+        values = {}
+        for i, d in enumerate(ds):
+            hashed = [public_inputs[w - 1] if w < n_pub else values[w]
+                      for w in vk.commitment_hashed[i]]
+            values[vk.commitment_wires[i]] = h2f.commitment_challenge(d, hashed)
+        extra = [values[w] for w in vk.commitment_wires]
+        # folded proof of knowledge: e(sum_i c^i D_i, [-sigma] g) . e(pok, g) == 1
+        ch = h2f.pok_challenge(extra)
+        folded, cp = None, 1
+        for d in ds:
+            folded = _g1_add(folded, _g1_mul(d, cp) if cp != 1 else d)
+            cp = cp * ch % R
+        if not pairing_product_is_one([(folded, g2_from_image(vk.commitment_g_sigma_neg)),
+                                       (pk_pt, g2_from_image(vk.commitment_g))]):
+            return False
     vk_x = ks[0]
-    for k, x in zip(ks[1:], public_inputs):
+    for k, x in zip(ks[1:], public_inputs + extra):
         vk_x = _g1_add(vk_x, _g1_mul(k, int(x)))
+    if n_com:
+        for d in ds:
+            vk_x = _g1_add(vk_x, d)
     pairs = [(_g1_neg(ar), bs),
              (g1_from_image(vk.g1_alpha), g2_from_image(vk.g2_beta)),
              (vk_x, g2_from_image(vk.g2_gamma)),

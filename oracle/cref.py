@@ -213,3 +213,64 @@ def groth16_prove_batch(h: R1csHandle, pk: PkHandle, inputs, rs, threads=0, msm_
     used = f(C.byref(h.s), C.byref(pk.s), _p(inputs), _p(rs), _p(proofs), _p(status),
              C.c_size_t(batch), int(threads), int(msm_c))
     return proofs, status, used
+
+
+# ---------------------------------------------------------------------------------------------
+# Groth16 commitment extension (oracle/c/zkref_prove.inc, second half)
+class CommitKey(C.Structure):
+    _fields_ = [("n_private", C.c_uint32), ("n_hashed", C.c_uint32), ("wire", C.c_uint32),
+                ("_pad", C.c_uint32), ("private_wires", C.c_void_p), ("hashed_wires", C.c_void_p),
+                ("basis", C.c_void_p), ("basis_exp_sigma", C.c_void_p)]
+
+
+class CommitKeysHandle:
+    """pk.commitment_keys (groth16.setup) as the C oracle's zkref_commit_key array"""
+
+    def __init__(self, pk):
+        self.keep = []
+        self.n = len(pk.commitment_keys)
+        self.arr = (CommitKey * max(self.n, 1))()
+        for i, ck in enumerate(pk.commitment_keys):
+            arrs = [np.ascontiguousarray(ck["private"], dtype=np.uint32),
+                    np.ascontiguousarray(ck["hashed"], dtype=np.uint32),
+                    np.ascontiguousarray(ck["basis"], dtype=np.uint64),
+                    np.ascontiguousarray(ck["basis_exp_sigma"], dtype=np.uint64)]
+            self.keep += arrs
+            self.arr[i] = CommitKey(len(ck["private"]), len(ck["hashed"]), ck["wire"], 0,
+                                    *[a.ctypes.data for a in arrs])
+
+
+def r1cs_solve_ex(h: R1csHandle, ck: CommitKeysHandle, inputs):
+    """-> (rc, wires, a, b, c, commitments [n_commitments, 8])"""
+    cc = h.cc
+    inputs = _u64(inputs)
+    w = np.zeros((cc.n_wires, 4), np.uint64)
+    a, b, c = (np.zeros((max(cc.n_constraints, 1), 4), np.uint64) for _ in range(3))
+    coms = np.zeros((max(ck.n, 1), 8), np.uint64)
+    f = lib().zkref_r1cs_solve_ex
+    f.restype = C.c_int
+    rc = f(C.byref(h.s), _p(inputs), _p(w), _p(a), _p(b), _p(c), ck.arr, C.c_uint32(ck.n), _p(coms))
+    return rc, w, a[:cc.n_constraints], b[:cc.n_constraints], c[:cc.n_constraints], coms[:ck.n]
+
+
+def groth16_prove_batch_ex(h: R1csHandle, pk: PkHandle, ck: CommitKeysHandle, inputs, rs, threads=0,
+                           msm_c=0):
+    """-> (proofs [batch, 32], commitments [batch, n, 8], poks [batch, 8], status, threads used)"""
+    inputs, rs = _u64(inputs), _u64(rs)
+    batch = inputs.shape[0]
+    proofs = np.zeros((batch, 32), np.uint64)
+    coms = np.zeros((batch, max(ck.n, 1), 8), np.uint64)
+    poks = np.zeros((batch, 8), np.uint64)
+    status = np.zeros(batch, np.int32)
+    f = lib().zkref_groth16_prove_batch_ex
+    f.restype = C.c_int
+    used = f(C.byref(h.s), C.byref(pk.s), ck.arr, C.c_uint32(ck.n), _p(inputs), _p(rs), _p(proofs),
+             _p(coms), _p(poks), _p(status), C.c_size_t(batch), int(threads), int(msm_c))
+    return proofs, coms[:, :ck.n], poks, status, used
+
+
+def hash_to_fr(msg: bytes, dst: bytes):
+    """fr.Hash(msg, dst, 1)[0] as a Montgomery element [4]"""
+    out = np.zeros(4, np.uint64)
+    lib().zkref_hash_to_fr(C.c_char_p(msg), C.c_size_t(len(msg)), C.c_char_p(dst), _p(out))
+    return out

@@ -1,0 +1,131 @@
+"""Groth16 commitment extension on the CPU side (gnark api.Commit, std/rangecheck,
+backend/groth16 with constraint.Groth16Commitments [UPSTREAM-RECALL]; reference call path
+ecc/secp256k1/ecdsa/address.go:14-40 -> utils/uints.go:14-28 -> uints.New -> rangecheck).  Parity is
+UNPINNED: the reference holds no commitment vector and gnark is not installed; what is checked is
+that four independent pieces agree -- the frontend's witness program (Python integers), the C
+oracle's gnark-style solver and prover, hash_to_field in Python and in C (RFC 9380 vectors), and
+the product's verifier."""
+import random
+
+import numpy as np
+
+from gnark_crypto_primitives_amd import groth16, hash_to_field, verify
+from gnark_crypto_primitives_amd.frontend import compile_circuit
+from gnark_crypto_primitives_amd.frontend.compile import (Public, Secret, array_to_ints,
+                                                          from_mont_array, to_mont_array)
+from gnark_crypto_primitives_amd.std import rangecheck, uints
+from oracle import cref
+from tests import helpers as H
+
+
+class RangeCircuit:
+    """two commitment-backed range checks (bytes of Y through uints.ValueOf, X + 3 < 2^13) around
+    one ordinary constraint"""
+    X = Public()
+    Y = Secret()
+
+    def define(self, api):
+        bf = uints.BinaryField(api, commit=True)
+        w = bf.ValueOf(self.Y)
+        rangecheck.New(api).Check(api.Add(self.X, 3), 13)
+        api.AssertIsEqual(api.Mul(w[0].Val, w[1].Val), self.X)
+
+
+class TwoCommitments:
+    """two api.Commit calls, the second one over a public wire, a private wire and the first
+    commitment's wire (PublicAndCommitmentCommitted)"""
+    X = Public()
+    Y = Secret()
+
+    def define(self, api):
+        y2 = api.Mul(self.Y, self.Y)
+        c1 = api.Commit(self.Y, y2)
+        t = api.Mul(c1, self.Y)
+        c2 = api.Commit(self.X, t, c1, api.Add(y2, 1))
+        api.AssertIsEqual(api.Mul(c2, 0), 0)
+        api.AssertIsEqual(api.Add(y2, 0), self.X)
+
+
+def _mul(g, s):
+    return cref.batch_mul(g, H.g1_gen_mont() if g == 1 else H.g2_gen_mont(), s)
+
+
+def test_hash_to_field_rfc9380_and_c_twin():
+    dst = b"QUUX-V01-CS02-with-expander-SHA256-128"
+    assert hash_to_field.expand_message_xmd(b"", dst, 0x20).hex() == \
+        "68a985b87eb6b46952128911f2a4412bbc302a9d759667f87f7a21d803f07235"
+    assert hash_to_field.expand_message_xmd(b"abc", dst, 0x20).hex() == \
+        "d8ccab23b5985ccea865c6c97b6e5b8350e794e603b4b97902f53a8a0d605615"
+    assert hash_to_field.expand_message_xmd(b"abcdef0123456789", dst, 0x80).hex().startswith(
+        "ef904a29bffc4cf9ee82832451c946ac3c8f8058ae97d8d629831a74c6572bd9")
+    rng = random.Random(5)
+    for n in (0, 1, 31, 32, 55, 56, 64, 96, 200):
+        msg = bytes(rng.getrandbits(8) for _ in range(n))
+        for d in (hash_to_field.COMMITMENT_DST, hash_to_field.POK_DST):
+            want = hash_to_field.hash_fr(msg, d)[0]
+            assert from_mont_array(cref.hash_to_fr(msg, d).reshape(1, 4))[0] == want
+
+
+def test_range_circuit_solvers_agree_and_proofs_verify():
+    for lanes in (1, 4, 16):
+        cc = compile_circuit(RangeCircuit(), lanes)
+        assert len(cc.commitments) == 1 and not cc.commitments[0]["hashed"]
+        pk, vk, _ = groth16.setup(cc, 9, _mul)
+        ck = pk.commitment_keys[0]
+        assert ck["basis"].shape == (len(ck["private"]), 8) and ck["wire"] not in pk.k_wire
+        assert not set(ck["private"]) & set(pk.k_wire.tolist())
+        assert len(vk.g1_k) == cc.n_public + 1
+        cc.commit_fn = groth16.commit_fn(pk)
+        rh, ph, ch = cref.R1csHandle(cc), cref.PkHandle(pk), cref.CommitKeysHandle(pk)
+        cases = [(0x11 * 0x22, 0x1122334455662211, True), (0x11 * 0x22 + 1, 0x2211, False),
+                 (0x11 * 0x22, 0x2211 + (1 << 64), False), (8184, 0x21f8, True),
+                 (8190, 0x2ac3, False)]
+        for x, y, ok in cases:
+            vec = cc.assignment_vector({"X": x, "Y": y})
+            w, a, b, c = cc.run_vprogram(vec)
+            assert (cc.last_status == 0) == ok
+            rc, ow, oa, ob, oc, coms = cref.r1cs_solve_ex(rh, ch, to_mont_array(vec))
+            assert (rc == 0) == ok, (x, y, rc)
+            if not ok:
+                continue
+            # same wires (commitment wire included: Pedersen MSM + hash agree) and same rows
+            assert from_mont_array(ow) == w
+            assert from_mont_array(oa) == a and from_mont_array(ob) == b and from_mont_array(oc) == c
+            assert cc.is_satisfied(w)[0]
+            d = verify.g1_from_image(coms[0])
+            assert w[ck["wire"]] == hash_to_field.commitment_challenge(d, [])
+        good = [c for c in cases if c[2]]
+        inp = np.stack([to_mont_array(cc.assignment_vector({"X": x, "Y": y})) for x, y, _ in good])
+        rs = np.stack([to_mont_array([7 + i, 11 + i]) for i in range(len(good))])
+        proofs, coms, poks, status, _ = cref.groth16_prove_batch_ex(rh, ph, ch, inp, rs)
+        assert not status.any()
+        for i, (x, y, _) in enumerate(good):
+            assert verify.verify(vk, [x], proofs[i], coms[i], poks[i])
+            assert not verify.verify(vk, [x + 1], proofs[i], coms[i], poks[i])
+            assert not verify.verify(vk, [x], proofs[i], coms[i], poks[1 - i])       # wrong PoK
+            assert not verify.verify(vk, [x], proofs[i], coms[1 - i], poks[i])       # wrong D
+            assert not verify.verify(vk, [x], proofs[i])                              # missing
+
+
+def test_two_commitments_second_one_hashes_public_and_first():
+    cc = compile_circuit(TwoCommitments())
+    assert len(cc.commitments) == 2
+    c1, c2 = cc.commitments
+    assert c1["hashed"] == [] and len(c1["private"]) == 2
+    assert c2["hashed"] == [1, c1["wire"]] and len(c2["private"]) == 2
+    pk, vk, _ = groth16.setup(cc, 10, _mul)
+    cc.commit_fn = groth16.commit_fn(pk)
+    rh, ph, ch = cref.R1csHandle(cc), cref.PkHandle(pk), cref.CommitKeysHandle(pk)
+    vec = cc.assignment_vector({"X": 49, "Y": 7})
+    w, *_ = cc.run_program(vec)
+    w2, *_ = cc.run_vprogram(vec)
+    assert w == w2 and cc.last_status == 0
+    rc, ow, *_rest, coms = cref.r1cs_solve_ex(rh, ch, to_mont_array(vec))
+    assert rc == 0 and from_mont_array(ow) == w
+    inp = to_mont_array(vec)[None]
+    rs = to_mont_array([3, 5])[None]
+    proofs, coms, poks, status, _ = cref.groth16_prove_batch_ex(rh, ph, ch, inp, rs)
+    assert not status.any()
+    assert verify.verify(vk, [49], proofs[0], coms[0], poks[0])
+    assert not verify.verify(vk, [50], proofs[0], coms[0], poks[0])
+    assert not verify.verify(vk, [49], proofs[0], coms[0][::-1].copy(), poks[0])
