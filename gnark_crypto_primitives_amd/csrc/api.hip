@@ -624,6 +624,7 @@ void zkmi_pk_free(zkmi_ctx* ctx, zkmi_pk* pk) {
   zkmi_msm_bases_free(ctx, pk->B2);
   zkmi_msm_bases_free(ctx, pk->D1);
   zkmi_msm_bases_free(ctx, pk->D2);
+  commit_keys_free(ctx, pk);
   if (pk->idx3) hipFree(pk->idx3);
   if (pk->a_wire) hipFree(pk->a_wire);
   if (pk->b_wire) hipFree(pk->b_wire);
@@ -696,12 +697,32 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
         return rc;
     }
     if (!d->k_wire) {
-      if (d->n_public < 1 || d->n_public > d->n_wires || d->n_wires - d->n_public != d->n_k) {
+      if (d->n_public < 1 || d->n_public > d->n_wires ||
+          (d->n_commitments == 0 && d->n_wires - d->n_public != d->n_k)) {
         ctx->err = "pk: without k_wire, n_public must satisfy n_wires - n_public == n_k";
         return ZKMI_ERR_ARG;
       }
-      wk.resize(d->n_k);
-      for (uint32_t i = 0; i < d->n_k; i++) wk[i] = d->n_public + i;
+      // gnark's setup leaves the private committed wires and the commitment wires out of G1.K
+      std::vector<uint8_t> taken(d->n_wires, 0);
+      for (uint32_t i = 0; i < d->n_commitments && d->commitments; i++) {
+        const zkmi_commitment_desc& c = d->commitments[i];
+        std::vector<uint32_t> pw(c.n_private);
+        if (c.n_private && (!c.private_wires || hipMemcpy(pw.data(), c.private_wires, (size_t)c.n_private * 4,
+                                                           hipMemcpyDefault) != hipSuccess)) {
+          ctx->err = "pk: cannot read the private wires of commitment " + std::to_string(i);
+          return ZKMI_ERR_ARG;
+        }
+        for (uint32_t w : pw)
+          if (w < d->n_wires) taken[w] = 1;
+        if (c.commitment_wire < d->n_wires) taken[c.commitment_wire] = 1;
+      }
+      wk.clear();
+      for (uint32_t w = d->n_public; w < d->n_wires; w++)
+        if (!taken[w]) wk.push_back(w);
+      if (wk.size() != d->n_k) {
+        ctx->err = "pk: n_k does not match n_wires - n_public - committed wires";
+        return ZKMI_ERR_ARG;
+      }
     }
     // every wire index is range-checked on the host before any kernel can use it as a row number
     for (auto& t : idx)
@@ -808,6 +829,10 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       return rc;
     }
   }
+  if ((rc = commit_keys_load(ctx, d, pk))) {
+    zkmi_pk_free(ctx, pk);
+    return rc;
+  }
   hipMemcpy(&pk->alpha, d->g1_alpha, 64, hipMemcpyDefault);
   hipMemcpy(&pk->beta1, d->g1_beta, 64, hipMemcpyDefault);
   hipMemcpy(&pk->delta1, d->g1_delta, 64, hipMemcpyDefault);
@@ -849,7 +874,9 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
     return ZKMI_ERR_ARG;
   }
   // validate every slot / constant / row index on the host before anything reaches a kernel
-  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV };
+  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT };
+  enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22 };
+  std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
   const uint32_t* p = d->program;
   const size_t stride = (size_t)(1 + S) * 4;
   std::vector<uint8_t> row_seen(d->n_constraints, 0);
@@ -886,6 +913,44 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
       for (uint32_t x : dsts)   // no dst aliases any src (dst rows are the prefix scratch)
         if (std::binary_search(srcs.begin(), srcs.end(), x)) return bad(r);
       r += nrows;
+      continue;
+    }
+    if (cls == CLS_HIST) {
+      // header (class, n queries, n rows, table size), quad 0 = (OP_HIST, first counter wire);
+      // the rows that follow hold the query slots; every quad carries class 0
+      const uint32_t nq = h[1], nrows = h[2], size = h[3];
+      const uint32_t* q0 = h + 4;
+      if (q0[0] != OP_HIST || size == 0 || (uint64_t)q0[1] + size > d->n_wires ||
+          nrows != (nq + S - 1) / S || (uint64_t)r + nrows > (uint64_t)d->n_rows - 1)
+        return bad(r);
+      for (uint32_t l = 1; l < S; l++)
+        if (h[4 * (1 + l)] != 0) return bad(r);
+      uint32_t seen = 0;
+      for (uint32_t t = 1; t <= nrows; t++) {
+        const uint32_t* hh = p + (size_t)(r + t) * stride;
+        if (hh[0] != (CLS_HIST | 0x100u)) return bad(r + t);
+        for (uint32_t l = 0; l < S; l++) {
+          const uint32_t* q = hh + 4 * (1 + l);
+          if (q[0] == OP_END) {
+            if (seen < nq && (t - 1) * S + l < nq) return bad(r + t);
+            continue;
+          }
+          if (q[0] != OP_HQ || q[2] >= d->n_slots || (t - 1) * S + l != seen) return bad(r + t);
+          seen++;
+        }
+      }
+      if (seen != nq) return bad(r);
+      r += nrows;
+      continue;
+    }
+    if (cls == CLS_COMMIT) {
+      // one row: header (class, n operands, 0, commitment index), quad 0 = (OP_COMMIT, wire, 0, index)
+      const uint32_t* q0 = h + 4;
+      if (q0[0] != OP_COMMIT || q0[1] >= d->n_wires || h[3] != commit_rows.size() || q0[3] != h[3])
+        return bad(r);
+      for (uint32_t l = 1; l < S; l++)
+        if (h[4 * (1 + l)] != 0) return bad(r);
+      commit_rows.emplace_back(r, q0[1]);
       continue;
     }
     if (cls < CLS_M || cls > CLS_BITS) return bad(r);
@@ -926,7 +991,10 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
                               : false;
           break;
         case CLS_BITS:
-          ok = l == 0 && op == OP_BITS && a < d->n_slots && b <= 256 && (uint64_t)dst + b <= d->n_slots;
+          // b = count | width << 16: count limbs of width bits (width 0 / 1: bits)
+          ok = l == 0 && op == OP_BITS && a < d->n_slots && (b >> 16) <= 16 && (b & 0xffffu) <= 256 &&
+               (uint64_t)(b & 0xffffu) * ((b >> 16) ? (b >> 16) : 1u) <= 256 &&
+               (uint64_t)dst + (b & 0xffffu) <= d->n_slots;
           break;
       }
       if (ok && emits) {
@@ -953,6 +1021,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   cs->n_rows = d->n_rows;
   cs->n_consts = d->n_consts;
   cs->lanes_per_proof = S;
+  cs->commit_rows = commit_rows;   // (row, commitment wire) in commitment order
   int rc = upload_u32(ctx, d->program, (size_t)d->n_rows * stride, &cs->program);
   if (rc) {
     delete cs;
@@ -994,6 +1063,11 @@ int zkmi_solve_batch(zkmi_ctx* ctx, const zkmi_cs* cs, const void* inputs, size_
     return ZKMI_ERR_ARG;
   }
   if (batch == 0) return ZKMI_OK;
+  if (!cs->commit_rows.empty()) {
+    ctx->err = "solve_batch: this system has commitments; its commitment wires come from the "
+               "proving key's Pedersen bases: use zkmi_prove_submit";
+    return ZKMI_ERR_ARG;
+  }
   const size_t Bp = round_up(batch, 64);
   const size_t n_in = cs->n_public - 1 + cs->n_secret;
   const size_t nc = cs->n_constraints ? cs->n_constraints : 1;
@@ -1053,6 +1127,17 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
     ctx->err = "prove: domain smaller than the number of constraints";
     return ZKMI_ERR_ARG;
   }
+  if (cs->commit_rows.size() != pk->commits.size()) {
+    ctx->err = "prove: the constraint system has " + std::to_string(cs->commit_rows.size()) +
+               " commitments, the proving key " + std::to_string(pk->commits.size());
+    return ZKMI_ERR_ARG;
+  }
+  for (size_t i = 0; i < pk->commits.size(); i++)
+    if (cs->commit_rows[i].second != pk->commits[i].wire) {
+      ctx->err = "prove: commitment " + std::to_string(i) + " lands on different wires in the "
+                 "constraint system and in the proving key";
+      return ZKMI_ERR_ARG;
+    }
   const int si = ctx->next_submit;
   zkmi_ctx::ProveSet& S = ctx->sets[si];
   if (S.pending) {
@@ -1113,18 +1198,36 @@ int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const
   rc = transpose_in(ctx, in_dev, (Fr*)S.slots + Bp, n_in, batch, Bp, 32);
   if (!rc) rc = rows_to_f_domain(ctx, (Fr*)S.slots + Bp, n_in, Bp);
   if (!rc) rc = transpose_in(ctx, rs_dev, S.rs, 2, batch, Bp, 32);
-  if (!rc)
-    rc = solve_bi(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp);
-  hipEventRecord(S.ev1, q);
-  ctx->stream = saved;
-  if (rc) return rc;
-  S.pending = true;
   S.batch = batch;
   S.Bp = Bp;
   S.pk = pk;
   S.cs = cs;
   S.n_constraints = cs->n_constraints;
   S.f_domain = true;
+  if (!rc && cs->commit_rows.empty()) {
+    rc = solve_bi(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp);
+  } else if (!rc) {
+    // commitment extension: the program stops at every COMMIT row; the commitment is an MSM over
+    // the wires solved so far, its hash becomes the commitment wire's value (commit.hip: the
+    // host blocks on this stream for the hash -- the main stream keeps running the previous
+    // batch's MSMs meanwhile)
+    rc = solve_init(ctx, (Fr*)S.slots, (int32_t*)S.st, Bp);
+    uint32_t begin = 0;
+    for (size_t i = 0; !rc && i < cs->commit_rows.size(); i++) {
+      rc = solve_rows(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp, begin,
+                      cs->commit_rows[i].first);
+      if (!rc) rc = commit_phase(ctx, S, (uint32_t)i, true);
+      begin = cs->commit_rows[i].first + 1;
+    }
+    if (!rc)
+      rc = solve_rows(ctx, cs, (Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c, (int32_t*)S.st, Bp, begin,
+                      cs->n_rows);
+    if (!rc) rc = commit_finish_submit(ctx, S);
+  }
+  hipEventRecord(S.ev1, q);
+  ctx->stream = saved;
+  if (rc) return rc;
+  S.pending = true;
   ctx->next_submit ^= 1;
   return ZKMI_OK;
 }
@@ -1202,6 +1305,7 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
       (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, v.tNRS)) ||
       (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, v.tS2)))
     return rc;
+  if ((rc = commit_pok(ctx, S))) return rc;   // commitment extension: proof of knowledge
   hipEventRecord(S.evq[4], ctx->stream);
   S.heavy_enqueued = true;
   return ZKMI_OK;
@@ -1212,11 +1316,20 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
 // and, when another batch is already submitted, that batch's quotient + MSM kernels are queued on
 // the main stream BEFORE waiting, so the assembly of batch k overlaps the quotient of batch k+1.
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
+  return zkmi_prove_collect_ex(ctx, proofs_out, status_out, nullptr);
+}
+
+int zkmi_prove_collect_ex(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out,
+                          void* commitments_out) {
   ZK_HIP(hipSetDevice(ctx->device));
   const int si = ctx->next_collect;
   zkmi_ctx::ProveSet& S = ctx->sets[si];
   if (!S.pending) {
     ctx->err = "prove: nothing submitted";
+    return ZKMI_ERR_ARG;
+  }
+  if (!S.pk->commits.empty() && !commitments_out) {
+    ctx->err = "prove: this key has commitments: collect with zkmi_prove_collect_ex";
     return ZKMI_ERR_ARG;
   }
   const zkmi_pk* pk = S.pk;
@@ -1257,6 +1370,15 @@ int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out) {
   ZK_HIP(hipGetLastError());
   ZK_HIP(hipMemcpyAsync(proofs_out, v.proofs, batch * 256, hipMemcpyDefault, q3));
   ZK_HIP(hipMemcpyAsync(status_out, S.st, batch * 4, hipMemcpyDefault, q3));
+  if (const size_t nc = pk->commits.size()) {
+    // per proof: Commitments[0 .. n-1], then CommitmentPok
+    const size_t pitch = (nc + 1) * 64;
+    for (size_t i = 0; i < nc; i++)
+      ZK_HIP(hipMemcpy2DAsync((char*)commitments_out + i * 64, pitch,
+                              (const char*)S.commit_pts + i * Bp * 64, 64, 64, batch, hipMemcpyDefault, q3));
+    ZK_HIP(hipMemcpy2DAsync((char*)commitments_out + nc * 64, pitch,
+                            (const char*)S.commit_pok + Bp * 128, 64, 64, batch, hipMemcpyDefault, q3));
+  }
   hipEventRecord(S.eva[1], q3);
   // look ahead: queue the next batch's heavy kernels before blocking on this batch's assembly
   zkmi_ctx::ProveSet& N = ctx->sets[si ^ 1];

@@ -1185,15 +1185,17 @@ int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
   chunks = (n + per_chunk - 1) / per_chunk;
   void* partial;
   // partials + room for the intermediate level of the reduction
-  int rc = ensure_scratch(ctx, 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
+  // side bases (commitment MSMs on the second stream) own scratch slot 18: the main stream may be
+  // running an MSM of the previous batch on slot 6 at the same time
+  int rc = ensure_scratch(ctx, bases->side ? 18 : 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
-  if (ctx->part_ev_valid[0]) {   // a deferred tail of an earlier MSM may still be reading this buffer
+  if (!bases->side && ctx->part_ev_valid[0]) {   // a deferred tail of an earlier MSM may still be reading this buffer
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[0], 0));
     ctx->part_ev_valid[0] = false;
   }
   const unsigned bx_cfg = 256;
   const unsigned bx = (Bp % bx_cfg == 0) ? bx_cfg : 64;
-  zkmi_ctx::ProveSet* es = ctx->msm_ev_set >= 0 ? &ctx->sets[ctx->msm_ev_set] : nullptr;
+  zkmi_ctx::ProveSet* es = (ctx->msm_ev_set >= 0 && !bases->side) ? &ctx->sets[ctx->msm_ev_set] : nullptr;
   const int ev = (es && n > 1 && es->msm_ev_used < 8) ? es->msm_ev_used++ : -1;
   if (ev >= 0) {
     es->msm_ev_group[ev] = bases->group;

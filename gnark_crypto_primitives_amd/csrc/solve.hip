@@ -84,7 +84,11 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // instruction, because the vector memory instructions of a wavefront reach the CU's L1 / the L2 in
 // issue order (a workgroup-scope fence here -- s_waitcnt vmcnt(0) after every step -- exposed the
 // store latency: 96 -> 7x ms per batch).
-enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV };
+enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT };
+// CLS_HIST / CLS_COMMIT do not fit the three class bits of an operand quad: their quads carry
+// class 0 and the class sits in the header quad.  OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22
+// (frontend/api.py).
+enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22 };
 
 // Stores of the hot step classes.  gfx950 reads the data registers of a vector store out of order
 // with later VGPR writes, so the compiler waits for a store to complete (s_waitcnt vmcnt) before it
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
                                                         Fr* __restrict__ a, Fr* __restrict__ b,
                                                         Fr* __restrict__ c,
                                                         int32_t* __restrict__ status, size_t Bp,
-                                                        uint32_t n_rows) {
+                                                        uint32_t n_rows, uint32_t row_begin,
+                                                        uint32_t row_end) {
   constexpr int PPW = 64 / S;   // proofs per wavefront
   const uint32_t sl = threadIdx.x / PPW;   // sub-lane
   const size_t lane = (size_t)blockIdx.x * PPW + (threadIdx.x % PPW);   // proof
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   const uint32_t total_q = n_rows * RQ;
   uint4 nx[NX];
   uint32_t cur = 0xffffffffu, pre = 0xffffffffu;   // chunk in LDS / chunk in nx (wave-uniform)
-  for (uint32_t r = 0; r < n_rows; r++) {
+  for (uint32_t r = row_begin; r < row_end; r++) {
     const uint32_t ci = r / CH;
     if (ci != cur) {
       if (ci != pre) {
@@ -273,14 +278,38 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
         break;
       case CLS_BITS: {
         // one instruction, quad of sub-lane 0: (dst0, src, n bits); the sub-lanes split the bits
+        // q0.w = count | width << 16: `count` limbs of `width` bits (width 0 / 1: bits)
         const uint4 q0 = prog[(size_t)r * (1 + S) + 1];
-        const uint32_t n = q0.w, per = (n + S - 1) / S;
+        const uint32_t n = q0.w & 0xffffu, wd = __builtin_amdgcn_readfirstlane(q0.w >> 16);
+        const uint32_t per = (n + S - 1) / S;
         const uint32_t i0 = sl * per, i1 = i0 + per < n ? i0 + per : n;
         const Fr v = f_plain(LD(q0.z));
         const Fr one = f_one(), zero = Fr::zero();
-        for (uint32_t i = i0; i < i1; i++) {
-          const uint32_t bit = i < 256 ? (v.v[i >> 5] >> (i & 31)) & 1u : 0u;
-          ST(q0.y + i, bit ? one : zero);
+        if (wd <= 1) {
+          for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t bit = i < 256 ? (v.v[i >> 5] >> (i & 31)) & 1u : 0u;
+            ST(q0.y + i, bit ? one : zero);
+          }
+        } else {
+          // limb i = bits [i wd, (i + 1) wd) of the integer (wd <= 16), as the F-domain image of
+          // that small integer: plain m times 2^522 through the F-domain product (. 2^-261)
+          constexpr uint32_t c522[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
+                                        0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};   // 2^522 mod r
+          Fr k522;
+#pragma unroll
+          for (int t = 0; t < 8; t++) k522.v[t] = c522[t];
+          for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t pos = i * wd;
+            uint32_t m = 0;
+            if (pos < 256) {
+              const uint32_t lo = v.v[pos >> 5], hi = (pos >> 5) < 7 ? v.v[(pos >> 5) + 1] : 0u;
+              const uint64_t two = ((uint64_t)hi << 32) | lo;
+              m = (uint32_t)(two >> (pos & 31)) & ((1u << wd) - 1u);
+            }
+            Fr pm = Fr::zero();
+            pm.v[0] = m;
+            ST(q0.y + i, fmul(pm, k522));
+          }
         }
         // compiler-visible stores: complete them here, or the register-reuse waits they force
         // (see st_acc) would reappear at the top of every following step
@@ -319,8 +348,41 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as after CLS_BITS
         break;
       }
-      default:
+      default: {
+        // class 0: the header quad names the class.  CLS_HIST: multiplicities of the table
+        // 0 .. size - 1 among hdr.y queries (the hdr.z rows that follow, S queries per row) into
+        // the consecutive wires starting at slot q0.y: the sub-lanes zero the counters, then
+        // sub-lane 0 counts query by query (a read-modify-write per query: the counters stay field
+        // elements of the value file, a query outside the table counts nowhere).  CLS_COMMIT rows
+        // are never executed: the host ends a launch in front of them.
+        const uint4 hdr = prog[(size_t)r * (1 + S)];
+        if ((hdr.x & 0xffu) == CLS_HIST && !(hdr.x & 0x100u)) {
+          const uint4 q0 = prog[(size_t)r * (1 + S) + 1];
+          const uint32_t nq = __builtin_amdgcn_readfirstlane(hdr.y);
+          const uint32_t nrows = __builtin_amdgcn_readfirstlane(hdr.z);
+          const uint32_t size = __builtin_amdgcn_readfirstlane(hdr.w);
+          const Fr zero = Fr::zero(), one = f_one();
+          for (uint32_t j = sl; j < size; j += S) ST(q0.y + j, zero);
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          if (sl == 0) {
+            const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1;
+            for (uint32_t t = 0; t < nq; t++) {
+              const uint4 p = pr[(size_t)(t / S) * (1 + S) + (t % S)];
+              if ((p.x & 0x1fu) != OP_HQ) continue;
+              const Fr v = f_plain(LD(p.z));
+              if ((v.v[1] | v.v[2] | v.v[3] | v.v[4] | v.v[5] | v.v[6] | v.v[7]) == 0 &&
+                  v.v[0] < size) {
+                ST(q0.y + v.v[0], add(LD(q0.y + v.v[0]), one));
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+              }
+            }
+          }
+          r += nrows;
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
         break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
@@ -392,17 +454,30 @@ __global__ void zero_status(int32_t* st, size_t n) {
   if (i < n) st[i] = 0;
 }
 
-int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
-             size_t Bp) {
+int solve_init(zkmi_ctx* ctx, Fr* slots, int32_t* status, size_t Bp) {
   hipLaunchKernelGGL(fill_one_row, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, slots, Bp);
   hipLaunchKernelGGL(zero_status, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, status, Bp);
+  ZK_HIP(hipGetLastError());
+  return ZKMI_OK;
+}
+
+int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
+             size_t Bp) {
+  int rc = solve_init(ctx, slots, status, Bp);
+  if (rc) return rc;
+  return solve_rows(ctx, cs, slots, a, b, c, status, Bp, 0, cs->n_rows);
+}
+
+int solve_rows(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
+               size_t Bp, uint32_t row_begin, uint32_t row_end) {
+  if (row_begin >= row_end) return ZKMI_OK;
   // one wavefront per 64 / S proofs
   const uint32_t S = cs->lanes_per_proof;
   const dim3 grid((unsigned)(Bp * S / 64)), block(64);
   const uint4* prog = (const uint4*)cs->program;
 #define ZK_SOLVE(SS)                                                                          \
   hipLaunchKernelGGL((solve_vliw_kernel<SS>), grid, block, 0, ctx->stream, prog, cs->consts, \
-                     slots, a, b, c, status, Bp, cs->n_rows)
+                     slots, a, b, c, status, Bp, cs->n_rows, row_begin, row_end)
   switch (S) {
     case 1: ZK_SOLVE(1); break;
     case 2: ZK_SOLVE(2); break;

@@ -447,6 +447,16 @@ int zkmi_prove_witness_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_r1cs*
                        (int32_t*)S.st, Bp);
     if (hipGetLastError() != hipSuccess) rc = ZKMI_ERR_HIP;
   }
+  S.batch = batch;
+  S.Bp = Bp;
+  S.pk = pk;
+  S.cs = nullptr;
+  S.n_constraints = n_constraints;
+  S.f_domain = false;
+  // commitment extension: the caller's solver has produced the commitment wires; the proof still
+  // needs the Pedersen commitments themselves and (several commitments) the folding challenge
+  for (size_t i = 0; !rc && i < pk->commits.size(); i++) rc = commit_phase(ctx, S, (uint32_t)i, false);
+  if (!rc && !pk->commits.empty()) rc = commit_finish_submit(ctx, S);
   hipEventRecord(S.ev1, ctx->stream);
   ctx->stream = saved;
   if (rc) {
@@ -455,12 +465,6 @@ int zkmi_prove_witness_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_r1cs*
     return rc;
   }
   S.pending = true;
-  S.batch = batch;
-  S.Bp = Bp;
-  S.pk = pk;
-  S.cs = nullptr;
-  S.n_constraints = n_constraints;
-  S.f_domain = false;
   ctx->next_submit ^= 1;
   return ZKMI_OK;
 }
@@ -480,6 +484,11 @@ int zkmi_prove_witness_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const void* wires
   }
   int rc = zkmi_prove_witness_submit(ctx, pk, nullptr, wires, a, b, c, n_constraints, batch, rs);
   if (rc) return rc;
+  if (!pk->commits.empty()) {
+    ctx->err = "prove_witness_batch: this key has commitments: use zkmi_prove_witness_submit + "
+               "zkmi_prove_collect_ex";
+    return ZKMI_ERR_ARG;
+  }
   std::vector<int32_t> status(batch);
   return zkmi_prove_collect(ctx, proofs_out, status.data());
 }

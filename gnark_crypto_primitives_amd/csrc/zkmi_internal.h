@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/zkmi.h"
@@ -54,7 +55,7 @@ struct zkmi_ctx {
   hipEvent_t ev[8] = {};
   double timings[8] = {};
   // scratch arena for the prove pipeline, grown on demand
-  zk::DevBuf scratch[20];
+  zk::DevBuf scratch[24];
   // software pipeline over batches: the latency-bound witness solve of batch k+1 runs on
   // `stream2` (16 wavefronts at batch 1024) underneath the NTT/MSM kernels of batch k.
   // `stream3` runs the 16-wavefront assembly of batch k underneath the quotient kernels of batch k+1.
@@ -75,6 +76,11 @@ struct zkmi_ctx {
     bool f_domain = true;             // value file and a, b, c in the solver's 2^261 domain
     void *slots = nullptr, *a = nullptr, *b = nullptr, *c = nullptr, *rs = nullptr, *st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // solve start / end on stream2
+    // commitment extension: Pedersen commitments of the batch (n_commitments x Bp G1 affine) and
+    // the per-proof powers of the folding challenge (n_commitments x Bp fr, in the value file's
+    // domain), written by the submit; proof of knowledge (Bp XYZZ -> affine) by the collect
+    void *commit_pts = nullptr, *commit_ch = nullptr, *commit_pok = nullptr, *commit_acc = nullptr;
+    std::vector<zk::Fr> commit_host;   // commitment wire values (plain integers), n x batch
   } sets[2];
   int next_submit = 0, next_collect = 0;
   // set whose proving-key MSM launches are currently being bracketed with HIP events (or null)
@@ -131,6 +137,18 @@ struct zkmi_msm_bases {
   uint32_t chunk_factor = 0;   // (window, chunk) blocks in flight / wave slots; 0 = default
   zk::G1Affine stotal1 = {};   // signed comb tables: sum of all bases (G1 / G2 by `group`)
   zk::G2Affine stotal2 = {};
+  // side = 1: per-window plan run on the second stream (commitment MSMs of a submit, beside the
+  // previous batch's MSMs on the main stream): its own partial-sum scratch, no deferred tails
+  int side = 0;
+};
+
+// one commitment of a key (zkmi_commitment_desc on the device)
+struct zkmi_commit_key {
+  uint32_t n_private = 0, n_hashed = 0, wire = 0;
+  std::vector<uint32_t> hashed;     // host copy (rows read back for the hash)
+  uint32_t* private_dev = nullptr;  // device: wire index of every basis point
+  zkmi_msm_bases* basis = nullptr;  // side tables
+  zkmi_msm_bases* sigma = nullptr;  // main-stream tables (proof of knowledge)
 };
 
 struct zkmi_pk {
@@ -141,6 +159,7 @@ struct zkmi_pk {
   uint32_t* idx3 = nullptr;                      // device {0, 1, 2}
   zk::G1Affine alpha, beta1, delta1;
   zk::G2Affine beta2, delta2;
+  std::vector<zkmi_commit_key> commits;   // commitment extension (empty for a plain key)
 };
 
 struct zkmi_cs {
@@ -148,6 +167,9 @@ struct zkmi_cs {
            n_consts = 0, lanes_per_proof = 1;
   uint32_t* program = nullptr;  // device
   zk::Fr* consts = nullptr;     // device
+  // COMMIT rows of the program in order: (row index, commitment index); the solver kernel is
+  // launched once per segment between them
+  std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
 };
 
 namespace zk {
@@ -255,6 +277,22 @@ int xyzz_to_affine(zkmi_ctx* ctx, int group, const void* in, void* out, size_t n
 // inputs must be converted with rows_to_f_domain after staging.
 int solve_bi(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
              size_t Bp);
+// the two halves of solve_bi for programs with COMMIT rows: initialise ONE row and status, then run
+// program rows [row_begin, row_end)
+int solve_init(zkmi_ctx* ctx, Fr* slots, int32_t* status, size_t Bp);
+int solve_rows(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c, int32_t* status,
+               size_t Bp, uint32_t row_begin, uint32_t row_end);
+
+// commit.hip: commitment extension of the prover
+// the commitments of set S at a COMMIT row of the solver path (or all of them, witness path):
+// MSM over the key's basis from the value file, hash_to_field on the host, challenge into the wire
+int commit_phase(zkmi_ctx* ctx, zkmi_ctx::ProveSet& S, uint32_t index, bool write_wire);
+// folding challenge powers for the proof of knowledge (after the last commit_phase)
+int commit_finish_submit(zkmi_ctx* ctx, zkmi_ctx::ProveSet& S);
+// proof of knowledge on ctx->stream (main stream, enqueue_heavy)
+int commit_pok(zkmi_ctx* ctx, zkmi_ctx::ProveSet& S);
+int commit_keys_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk* pk);
+void commit_keys_free(zkmi_ctx* ctx, zkmi_pk* pk);
 int rows_to_f_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp);
 int rows_to_std_domain(zkmi_ctx* ctx, Fr* base, size_t rows, size_t Bp);
 int array_to_f_domain(zkmi_ctx* ctx, Fr* a, size_t n);

@@ -242,6 +242,20 @@ class Prover:
             self._keep += [inf_a, inf_b]
             ptrs[0] = ptrs[1] = ptrs[2] = None
             n_public = cc.n_public
+        # commitment extension: pk.CommitmentKeys + the wire lists of constraint.Groth16Commitments
+        self.n_commitments = len(pk.commitment_keys)
+        cdescs = (_lib.CommitmentDesc * max(self.n_commitments, 1))()
+        for i, ck in enumerate(pk.commitment_keys):
+            arrs = [np.ascontiguousarray(ck["private"], dtype=np.uint32),
+                    np.ascontiguousarray(ck["hashed"], dtype=np.uint32),
+                    np.ascontiguousarray(ck["basis"], dtype=np.uint64),
+                    np.ascontiguousarray(ck["basis_exp_sigma"], dtype=np.uint64)]
+            self._keep += arrs
+            cdescs[i] = _lib.CommitmentDesc(len(ck["private"]), len(ck["hashed"]), ck["wire"], 0,
+                                            *[a.ctypes.data for a in arrs])
+        self._keep.append(cdescs)
+        if len(getattr(cc, "commitments", [])) != self.n_commitments:
+            raise ValueError("circuit and proving key disagree on the number of commitments")
         pd = _lib.PkDesc(pk.log_n, pk.n_wires, len(pk.a_wire), len(pk.b_wire), len(pk.k_wire),
                          pk.g1_z.shape[0], *ptrs, window_bits_g1, window_bits_g2,
                          inf_a.ctypes.data if inf_a is not None else None,
@@ -249,7 +263,9 @@ class Prover:
                          max_batch, table_budget_bytes, cc.v_n_slots, msm_chunk_factor,
                          (2 if cc.n_boolean_wires * 100 >= cc.n_wires * 99 else
                           int(cc.n_boolean_wires * 2 > cc.n_wires)) if sparse_witness is None
-                         else int(sparse_witness))
+                         else int(sparse_witness),
+                         self.n_commitments,
+                         C.addressof(cdescs) if self.n_commitments else None)
         self.pk_h = ctx.pk_load(pd)
 
     def load_r1cs(self):
@@ -296,6 +312,9 @@ class Prover:
         batch = inputs.shape[0]
         self._check_batch(inputs, (batch, self.n_inputs, 4), "inputs")
         self._check_batch(rs, (batch, 2, 4), "rs")
+        if self.n_commitments:          # keys with commitments: the pipelined pair, three outputs
+            self.submit(inputs, rs)
+            return self.collect(proofs_out, status_out)
         if proofs_out is None:
             proofs_out = np.zeros((batch, 32), dtype=np.uint64)
         if status_out is None:
@@ -358,13 +377,20 @@ class Prover:
         self._inflight = getattr(self, "_inflight", [])
         self._inflight.append((inputs, rs, inputs.shape[0]))     # keep buffers alive
 
-    def collect(self, proofs_out=None, status_out=None):
-        """Stage 2 (quotient, MSMs, assembly) of the oldest submitted batch."""
+    def collect(self, proofs_out=None, status_out=None, commitments_out=None):
+        """Stage 2 (quotient, MSMs, assembly) of the oldest submitted batch.  Keys with the
+        commitment extension return (proofs, status, commitments): commitments[p] = uint64
+        [n_commitments + 1, 8]: proof.Commitments then proof.CommitmentPok."""
         _, _, batch = self._inflight.pop(0)
         if proofs_out is None:
             proofs_out = np.zeros((batch, 32), dtype=np.uint64)
         if status_out is None:
             status_out = np.zeros(batch, dtype=np.int32)
+        if self.n_commitments:
+            if commitments_out is None:
+                commitments_out = np.zeros((batch, self.n_commitments + 1, 8), dtype=np.uint64)
+            self.ctx.prove_collect(proofs_out, status_out, commitments_out)
+            return proofs_out, status_out, commitments_out
         self.ctx.prove_collect(proofs_out, status_out)
         return proofs_out, status_out
 

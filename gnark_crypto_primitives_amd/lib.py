@@ -29,7 +29,15 @@ class PkDesc(C.Structure):
                 ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p), ("n_public", C.c_uint32),
                 ("max_batch", C.c_uint32), ("table_budget_bytes", C.c_uint64),
                 ("n_slots_hint", C.c_uint32), ("msm_chunk_factor", C.c_uint32),
-                ("sparse_witness", C.c_uint32)]
+                ("sparse_witness", C.c_uint32), ("n_commitments", C.c_uint32),
+                ("commitments", C.c_void_p)]
+
+
+class CommitmentDesc(C.Structure):
+    _fields_ = [("n_private", C.c_uint32), ("n_hashed", C.c_uint32),
+                ("commitment_wire", C.c_uint32), ("reserved", C.c_uint32),
+                ("private_wires", C.c_void_p), ("hashed_wires", C.c_void_p),
+                ("basis", C.c_void_p), ("basis_exp_sigma", C.c_void_p)]
 
 
 class CsDesc(C.Structure):
@@ -71,6 +79,7 @@ SYMBOLS = [
     ("zkmi_prove_batch", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P]),
     ("zkmi_prove_submit", _I, [_P, _P, _P, _P, _SZ, _P]),
     ("zkmi_prove_collect", _I, [_P, _P, _P]),
+    ("zkmi_prove_collect_ex", _I, [_P, _P, _P, _P]),
     ("zkmi_prove_witness_batch", _I, [_P, _P, _P, _P, _P, _P, _SZ, _SZ, _P, _P]),
     ("zkmi_host_alloc", _P, [_P, _SZ]),
     ("zkmi_host_free", None, [_P, _P]),
@@ -243,9 +252,14 @@ class Context:
         self._check(self.lib.zkmi_prove_submit(self.h, pk_h, cs_h, _ptr(inputs), batch, _ptr(rs)),
                     "zkmi_prove_submit")
 
-    def prove_collect(self, proofs_out, status_out):
-        self._check(self.lib.zkmi_prove_collect(self.h, _ptr(proofs_out), _ptr(status_out)),
-                    "zkmi_prove_collect")
+    def prove_collect(self, proofs_out, status_out, commitments_out=None):
+        if commitments_out is None:
+            self._check(self.lib.zkmi_prove_collect(self.h, _ptr(proofs_out), _ptr(status_out)),
+                        "zkmi_prove_collect")
+        else:
+            self._check(self.lib.zkmi_prove_collect_ex(self.h, _ptr(proofs_out), _ptr(status_out),
+                                                       _ptr(commitments_out)),
+                        "zkmi_prove_collect_ex")
 
     def prove_witness_batch(self, pk_h, wires, a, b, c, n_constraints, batch, rs, proofs_out):
         self._check(self.lib.zkmi_prove_witness_batch(self.h, pk_h, _ptr(wires), _ptr(a), _ptr(b),

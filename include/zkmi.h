@@ -106,6 +106,25 @@ int zkmi_fixed_base_mul(zkmi_ctx* ctx, int group, const void* base, const void* 
  *     (pk.G1.K holds wires n_public .. n_wires-1 in order) with k_wire = NULL;
  *   - or explicit index arrays a_wire / b_wire / k_wire (what this repo's own setup emits).
  * n_a / n_b / n_k are always the lengths of g1_a / g1_b (= g2_b) / g1_k. */
+/* One commitment of gnark's Groth16 commitment extension (api.Commit; std/rangecheck and the
+ * lookup arguments build on it): constraint.Groth16Commitment {PrivateCommitted,
+ * PublicAndCommitmentCommitted, CommitmentIndex} and pedersen.ProvingKey {Basis, BasisExpSigma} of
+ * pk.CommitmentKeys[i] [UPSTREAM-RECALL, SURVEY.md §3.2 step 6].  The prover commits to the private
+ * wires (MSM over basis), derives the commitment wire's value by hash_to_field over the commitment
+ * and the hashed wires' values (RFC 9380 expand_message_xmd, SHA-256, DST "bsb22-commitment"), and
+ * proves knowledge with the same scalars over basis_exp_sigma (folded over all commitments with
+ * powers of Hash(commitment wire values, DST "G16-BSB22")). */
+typedef struct {
+  uint32_t n_private;            /* basis points = committed private wires */
+  uint32_t n_hashed;             /* public wires / earlier commitment wires hashed with it */
+  uint32_t commitment_wire;      /* wire that receives the challenge */
+  uint32_t reserved;
+  const uint32_t* private_wires; /* n_private wire indices, basis order */
+  const uint32_t* hashed_wires;  /* n_hashed wire indices */
+  const void* basis;             /* n_private G1 affine */
+  const void* basis_exp_sigma;   /* n_private G1 affine */
+} zkmi_commitment_desc;
+
 typedef struct {
   uint32_t log_n;       /* domain size 2^log_n */
   uint32_t n_wires;     /* columns of the constraint system, including ONE */
@@ -152,6 +171,10 @@ typedef struct {
    * quotient MSM, whose scalars are dense, takes the freed HBM with its own, wider plan.
    * 0 = dense field elements (Poseidon). */
   uint32_t sparse_witness;
+  /* Commitment extension: 0 / NULL for a plain Groth16 key.  With k_wire = NULL the library leaves
+   * the private committed wires and the commitment wires out of pk.G1.K, as gnark's setup does. */
+  uint32_t n_commitments;
+  const zkmi_commitment_desc* commitments;
 } zkmi_pk_desc;
 /* Copies the key to the device and builds the MSM window tables; host buffers may be freed
  * afterwards.  One-off per circuit (gnark's icicle backend does the same lazily). */
@@ -170,7 +193,10 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
  * the GPU runs a step with that many lanes of a wavefront per proof.
  *   program: n_rows x (1 + lanes_per_proof) x 4 words.  Row = header (class, active, aux, 0) +
  *   one operand quad per sub-lane (op | check << 5 | class << 6 | constraint_row << 9, dst slot,
- *   a, b). */
+ *   a, b).  Systems with commitments hold one COMMIT row per commitment (header class 9, aux =
+ *   commitment index): the solver stops in front of it, the prover commits, hashes, writes the
+ *   challenge into the commitment wire and resumes (zkmi_prove_submit needs a key whose
+ *   n_commitments matches). */
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
   uint32_t n_slots, n_rows, n_consts;
@@ -209,6 +235,11 @@ int zkmi_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const 
 int zkmi_prove_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_cs* cs, const void* inputs,
                       size_t batch, const void* rs);
 int zkmi_prove_collect(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out);
+/* The same for keys with the commitment extension: commitments_out receives, per proof,
+ * (n_commitments + 1) G1 affine points: proof.Commitments[0..n-1] then proof.CommitmentPok.
+ * zkmi_prove_collect on such a key returns ZKMI_ERR_ARG (a proof without them cannot verify). */
+int zkmi_prove_collect_ex(zkmi_ctx* ctx, void* proofs_out, int32_t* status_out,
+                          void* commitments_out);
 
 /* -- the gnark drop-in entry: prove from SOLVED witnesses --------------------------------------- */
 /* For a caller that keeps gnark's own solver (cs.Solve -> solution.W, and optionally solution.A,

@@ -31,6 +31,8 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     from gnark_crypto_primitives_amd import plonk
     fields = {"zkmi_pk_desc": [n for n, _ in lib.PkDesc._fields_],
+              "zkmi_commitment_desc": [n for n, _ in lib.CommitmentDesc._fields_],
+              "zkmi_r1cs_desc": [n for n, _ in lib.R1csDesc._fields_],
               "zkmi_cs_desc": [n for n, _ in lib.CsDesc._fields_],
               "zkmi_plonk_pk_desc": [n for n, _ in plonk.PlonkDesc._fields_]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "zkmi.h"', 'int main(void) {']
@@ -45,6 +47,7 @@ def test_struct_layouts_match_header(tmp_path):
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     for st, cls in (("zkmi_pk_desc", lib.PkDesc), ("zkmi_cs_desc", lib.CsDesc),
+                    ("zkmi_commitment_desc", lib.CommitmentDesc), ("zkmi_r1cs_desc", lib.R1csDesc),
                     ("zkmi_plonk_pk_desc", plonk.PlonkDesc)):
         assert int(out[st]) == C.sizeof(cls), st
         for f in fields[st]:
