@@ -494,6 +494,9 @@ def main():
     inp_d, rs_d = to_dev(inp_h), to_dev(rs_h)
     proofs_d = torch.zeros((B, 32), dtype=torch.int64, device=dev)
     status_d = torch.zeros(B, dtype=torch.int32, device=dev)
+    # keys with the commitment extension also return proof.Commitments and proof.CommitmentPok
+    coms_d = torch.zeros((B, prover.n_commitments + 1, 8), dtype=torch.int64, device=dev) \
+        if prover.n_commitments else None
     torch.cuda.synchronize()
     log(f"witnesses resident ({time.time() - t0:.1f}s)")
     gather = pg and not args.no_gather
@@ -521,6 +524,13 @@ def main():
         startup["witness_solve_s"] = time.time() - t1
         log(f"solved witnesses on the host: {sum(x.nbytes for x in arrs) / 1e9:.2f} GB "
             f"({args.host_mem}) ({time.time() - t0:.1f}s)")
+
+    def prove_blocking(inp, rsd):
+        if coms_d is None:
+            prover.prove(inp, rsd, proofs_d, status_d)
+        else:
+            prover.submit(inp, rsd)
+            prover.collect(proofs_d, status_d, coms_d)
 
     def submit(inp, rsd):
         if wit is None:
@@ -554,10 +564,10 @@ def main():
         elif args.no_pipeline:
             for _ in range(steps):
                 if wit is None:
-                    prover.prove(inp, rsd, proofs_d, status_d)
+                    prove_blocking(inp, rsd)
                 else:
                     submit(inp, rsd)
-                    prover.collect(proofs_d, status_d)
+                    prover.collect(proofs_d, status_d, coms_d)
                 stage += np.array(ctx.last_timings())
                 finish_step()
         else:
@@ -565,7 +575,7 @@ def main():
             for k in range(steps):
                 if k + 1 < steps:
                     submit(inp, rsd)
-                prover.collect(proofs_d, status_d)
+                prover.collect(proofs_d, status_d, coms_d)
                 stage += np.array(ctx.last_timings())
                 finish_step()
         torch.cuda.synchronize()
@@ -585,10 +595,10 @@ def main():
     # solve is exposed, nothing of the timed work happens outside the region.
     for _ in range(args.warmup):
         if B and wit is None:
-            prover.prove(inp_d, rs_d, proofs_d, status_d)
+            prove_blocking(inp_d, rs_d)
         elif B:
             submit(inp_d, rs_d)
-            prover.collect(proofs_d, status_d)
+            prover.collect(proofs_d, status_d, coms_d)
         finish_step()
     elapsed, stage = timed_steps(args.steps, inp_d, rs_d)
     status = status_d.cpu().numpy()
@@ -611,7 +621,7 @@ def main():
     worst = None
     if wc_steps:
         inp_w = to_dev(np.stack(sets["worst"]))
-        prover.prove(inp_w, rs_d, proofs_d, status_d)
+        prove_blocking(inp_w, rs_d)
         e_w, st_w = timed_steps(wc_steps, inp_w, rs_d)
         bad_w = int((status_d.cpu().numpy() != 0).sum())
         worst = {"value": global_batch * wc_steps / e_w, "steps": wc_steps,
@@ -627,7 +637,7 @@ def main():
         prover = groth16.Prover(ctx, cc, pk, 0, 0, max_batch=max(B, 64),
                                 table_budget_bytes=int(args.bounded_gb * 1e9))
         info_b = ctx.pk_info(prover.pk_h)
-        prover.prove(inp_d, rs_d, proofs_d, status_d)
+        prove_blocking(inp_d, rs_d)
         e_b, _ = timed_steps(args.bounded_steps, inp_d, rs_d)
         same = bool(np.array_equal(proofs_d.cpu().numpy().view(np.uint64), proofs))
         bounded = {"table_budget_gb": args.bounded_gb, "value": B * args.bounded_steps / e_b,
@@ -694,9 +704,16 @@ def main():
             S = args.cpu_sample if args.cpu_sample > 0 else min(B, 2 * cores)
             rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
             tc = time.perf_counter()
-            want, wstatus, used = cref.groth16_prove_batch(rh, ph, inp_h[:S], rs_h[:S], cores)
+            if prover.n_commitments:
+                want, wcoms, wpoks, wstatus, used = cref.groth16_prove_batch_ex(
+                    rh, ph, cref.CommitKeysHandle(pk), inp_h[:S], rs_h[:S], cores)
+                got_c = coms_d.cpu().numpy().view(np.uint64)[:S]
+                same = bool(np.array_equal(got_c[:, :-1], wcoms) and np.array_equal(got_c[:, -1], wpoks))
+            else:
+                want, wstatus, used = cref.groth16_prove_batch(rh, ph, inp_h[:S], rs_h[:S], cores)
+                same = True
             tc = time.perf_counter() - tc
-            same = bool(np.array_equal(want, proofs[:S]) and not wstatus.any())
+            same = bool(same and np.array_equal(want, proofs[:S]) and not wstatus.any())
             cpu = {"value": S / tc, "unit": "proofs/s", "cores": used, "kind": "port",
                    "sample": f"first {S} proofs of the same batch, C oracle (oracle/c), "
                              f"OpenMP over proofs", "seconds": tc,

@@ -9,7 +9,8 @@ from .std.emulated import limbs_of
 from .tree import smt_witness
 
 R = poseidon_native.R
-NAMES = ("arbo", "poseidon", "verifier", "elgamal-add", "elgamal-encrypt", "address")
+NAMES = ("arbo", "poseidon", "verifier", "elgamal-add", "elgamal-encrypt", "address",
+         "address-commit")
 
 
 def _poseidon(rng):
@@ -74,4 +75,8 @@ def build(name, levels=160, populated=10):
     if name == "address":
         return (circuits.AddressCircuit(), _address,
                 "secp256k1 address derivation, Keccak-256 in R1CS (config 5)")
+    if name == "address-commit":
+        return (circuits.AddressCircuitCommit(), _address,
+                "secp256k1 address derivation, Keccak-256 in R1CS, bytes range-checked through "
+                "gnark's commitment-based checker (config 5 with the Groth16 commitment extension)")
     raise ValueError(f"unknown workload {name!r}; one of {NAMES}")

@@ -10,7 +10,8 @@
 // It builds the circuit of tree/test/verifier_bn254_test.go:23-34 with Siblings[levels], makes
 // synthetic inclusion paths of the shape SURVEY.md §8d describes (k populated siblings, root
 // folded with iden3 Poseidon as in tree/smt/verifier_level.go), runs groth16.Setup once, then
-// (1) groth16.Prove per witness on all cores, (2) zkmi.ProveBatch on GPU 0, verifies every proof
+// (1) groth16.Prove per witness on all cores, (2) zkmi.Prover (Submit / Collect, two batches in
+// flight) on GPU 0, verifies every proof
 // with groth16.Verify, and prints both rates.
 package main
 
@@ -125,17 +126,32 @@ func main() {
 	dev, err := zkmi.Open(0)
 	must(err)
 	defer dev.Close()
-	key, err := dev.LoadKey(pk.(*groth16_bn254.ProvingKey), ccs.GetNbPublicVariables(),
-		ccs.GetNbConstraints(), *batch)
+	r1 := ccs.(*cs_bn254.R1CS)
+	key, err := dev.LoadKey(pk.(*groth16_bn254.ProvingKey), r1, *batch, 0)
 	must(err)
+	mats, err := dev.LoadR1CS(r1) // L, R, O resident: a batch ships its wire vectors only
+	must(err)
+	prover, err := dev.NewProver(r1, key, mats, *batch)
+	must(err)
+	defer prover.Close()
 	rs := make([]fr.Element, 2**batch)
 	for i := range rs {
 		rs[i].SetRandom()
 	}
+	// two batches in flight: batch k+1's CPU solve and PCIe transfer run under batch k's MSM kernels
 	t0 = time.Now()
-	proofs, err := dev.ProveBatch(ccs.(*cs_bn254.R1CS), key, ws, rs)
+	must(prover.Submit(ws, rs))
+	must(prover.Submit(ws, rs))
+	proofs, status, err := prover.Collect()
 	must(err)
-	gpu := time.Since(t0)
+	_, _, err = prover.Collect()
+	must(err)
+	gpu := time.Since(t0) / 2
+	for _, st := range status {
+		if st != 0 {
+			panic("unsatisfied witness")
+		}
+	}
 	for i := range proofs {
 		pub, _ := ws[i].Public()
 		must(groth16.Verify(&proofs[i], vk, pub))

@@ -823,3 +823,4 @@ void zkref_g2_add(const uint64_t* a, const uint64_t* b, uint64_t* out) {
 }
 
 #include "zkref_prove.inc"
+#include "zkref_plonk.inc"

@@ -290,6 +290,149 @@ def prove(key, a, b, c, public, blind):
             "wz": commit(srs, wz), "wzw": commit(srs, wzw), "ev": ev}
 
 
+def setup_fast(scs, srs_img, com, g2_tau):
+    """Oracle key for ``prove_fast`` at sizes where ``setup``'s Python NTTs are too slow: selector
+    and permutation polynomials from the circuit (Lagrange values built here, inverse NTTs in the C
+    oracle); the SRS image, the eight key commitments and [tau]_2 are taken as data (they are compared
+    with ``setup``'s on the small circuits of tests/test_gpu_plonk.py)."""
+    import ctypes as C
+    n, log_n = 1 << scs.log_n, scs.log_n
+    w = root(log_n)
+    ident = []
+    for c in range(3):
+        x = K[c]
+        for _ in range(n):
+            ident.append(x)
+            x = x * w % R
+    sig = [[ident[int(scs.sigma[c * n + r])] for r in range(n)] for c in range(3)]
+    lag = {"ql": scs.qL, "qr": scs.qR, "qo": scs.qO, "qm": scs.qM, "qc": scs.qC,
+           "s1": sig[0], "s2": sig[1], "s3": sig[2]}
+    lag_m = {k: mont([int(x) % R for x in v]) for k, v in lag.items()}
+    coef_m = {}
+    for k, v in lag_m.items():
+        cf = v.copy()
+        cref.lib().zkref_ntt(cf.ctypes.data_as(C.c_void_p), log_n, 1, 0)
+        coef_m[k] = cf
+    return {"log_n": log_n, "n_pub": scs.n_public - 1, "srs": srs_img, "com": com, "g2_tau": g2_tau,
+            "coef_m": coef_m, "sig_m": np.concatenate([lag_m[k] for k in ("s1", "s2", "s3")]),
+            "sel_m": np.concatenate([coef_m[k] for k in
+                                     ("ql", "qr", "qo", "qm", "qc", "s1", "s2", "s3")])}
+
+
+# ---- the same prover with its per-element loops in C (oracle/c/zkref_plonk.inc) -----------------------
+def _unmont(arr):
+    return cref_ints(cref.fr_from_mont(arr))
+
+
+def cref_ints(arr):
+    a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+    return [int.from_bytes(a[i].tobytes(), "little") for i in range(a.shape[0])]
+
+
+def _m1(x):
+    return mont([x])[0]
+
+
+def prove_fast(key, a, b, c, public, blind):
+    """``prove`` with NTTs, grand product, quotient, evaluations and divisions in the C oracle; the
+    protocol, the transcript and every formula are those of ``prove`` above (tests/test_plonk.py
+    compares the two on small circuits), so BASELINE config 5 at 2^18 gates takes seconds."""
+    import ctypes as C
+    lib = cref.lib()
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    log_n = key["log_n"]
+    n = 1 << log_n
+    w = root(log_n)
+    srs = key["srs"]
+    if "coef_m" not in key:
+        key["coef_m"] = {k: mont(v) for k, v in key["coef"].items()}
+        key["sig_m"] = np.concatenate([mont(key["lag"][k]) for k in ("s1", "s2", "s3")])
+        key["sel_m"] = np.concatenate([key["coef_m"][k] for k in
+                                       ("ql", "qr", "qo", "qm", "qc", "s1", "s2", "s3")])
+    coef_m = key["coef_m"]
+
+    def blinded(vals_m, bs):
+        cf = np.zeros((n + len(bs), 4), np.uint64)
+        cf[:len(vals_m)] = vals_m
+        head = np.ascontiguousarray(cf[:n])
+        lib.zkref_ntt(P(head), log_n, 1, 0)
+        cf[:n] = head
+        for j, bj in enumerate(reversed(bs)):
+            lo = _unmont(cf[j:j + 1])[0]
+            cf[j] = _m1(lo - bj)
+            cf[n + j] = _m1(bj)
+        return cf
+
+    def commit_m(cf):
+        return g1_from_image(cref.msm(1, srs[:len(cf)], cf))
+
+    def ev_at(cf, x):
+        out = np.zeros(4, np.uint64)
+        xm = _m1(x)
+        lib.zkref_poly_eval(P(np.ascontiguousarray(cf)), C.c_size_t(len(cf)), P(xm), P(out))
+        return _unmont(out)[0]
+    am, bm, cm = (mont(list(v)) for v in (a, b, c))
+    ca, cb, cc = blinded(am, blind[0:2]), blinded(bm, blind[2:4]), blinded(cm, blind[4:6])
+    A, B, Cc = commit_m(ca), commit_m(cb), commit_m(cc)
+    vkd = vk_digest(key)
+    gamma = challenge("gamma", vkd, *public, A, B, Cc)
+    beta = challenge("beta", gamma)
+    cols = np.zeros((3, n, 4), np.uint64)
+    for k, v in enumerate((am, bm, cm)):
+        cols[k, :len(v)] = v
+    z = np.zeros((n, 4), np.uint64)
+    lib.zkref_plonk_z(P(cols), P(key["sig_m"]), P(_m1(beta)), P(_m1(gamma)), log_n, P(z))
+    cz = blinded(z, blind[6:9])
+    Z = commit_m(cz)
+    alpha = challenge("alpha", beta, Z)
+    pi_l = np.zeros((n, 4), np.uint64)
+    if public:
+        pi_l[:len(public)] = mont([(-v) % R for v in public])
+    lib.zkref_ntt(P(pi_l), log_n, 1, 0)
+    ct = np.zeros((4 * n, 4), np.uint64)
+    lib.zkref_plonk_quotient(P(ca), P(cb), P(cc), C.c_size_t(len(ca)), P(cz), C.c_size_t(len(cz)),
+                             P(pi_l), P(key["sel_m"]), P(_m1(beta)), P(_m1(gamma)), P(_m1(alpha)),
+                             log_n, P(ct))
+    assert not ct[3 * n + 6:].any(), "quotient degree too high: the witness does not satisfy the system"
+    tlo, tmid, thi = (np.ascontiguousarray(x) for x in
+                      (ct[:n + 2], ct[n + 2:2 * n + 4], ct[2 * n + 4:3 * n + 6]))
+    TLO, TMID, THI = commit_m(tlo), commit_m(tmid), commit_m(thi)
+    zeta = challenge("zeta", alpha, TLO, TMID, THI)
+    ev = (ev_at(ca, zeta), ev_at(cb, zeta), ev_at(cc, zeta), ev_at(coef_m["s1"], zeta),
+          ev_at(coef_m["s2"], zeta), ev_at(cz, zeta * w % R))
+    v = challenge("v", zeta, *ev)
+    sc = lin_scalars(key, public, beta, gamma, alpha, zeta, ev)
+    L = n + 3
+    r = np.zeros((L, 4), np.uint64)
+
+    def axpy(dst, p, s):
+        p = np.ascontiguousarray(p)
+        lib.zkref_poly_axpy(P(dst), P(p), C.c_size_t(len(p)), P(_m1(s)))
+    for name, s_ in (("qm", sc["qm"]), ("ql", sc["ql"]), ("qr", sc["qr"]), ("qo", sc["qo"]),
+                     ("qc", 1), ("s3", sc["s3"])):
+        axpy(r, coef_m[name], s_)
+    axpy(r, cz, sc["z"])
+    for p_, s_ in ((tlo, sc["tlo"]), (tmid, sc["tmid"]), (thi, sc["thi"])):
+        axpy(r, p_, s_)
+    r[0] = _m1(_unmont(r[0:1])[0] + sc["r0"])
+    assert ev_at(r, zeta) == 0
+    num = r.copy()
+    vp, shift = 1, 0
+    for p_, e in ((ca, ev[0]), (cb, ev[1]), (cc, ev[2]), (coef_m["s1"], ev[3]), (coef_m["s2"], ev[4])):
+        vp = vp * v % R
+        axpy(num, p_, vp)
+        shift = (shift + vp * e) % R
+    num[0] = _m1(_unmont(num[0:1])[0] - shift)
+    wz = np.zeros((L - 1, 4), np.uint64)
+    lib.zkref_div_linear(P(num), C.c_size_t(L), P(_m1(zeta)), P(wz))
+    nz = cz.copy()
+    nz[0] = _m1(_unmont(nz[0:1])[0] - ev[5])
+    wzw = np.zeros((len(nz) - 1, 4), np.uint64)
+    lib.zkref_div_linear(P(nz), C.c_size_t(len(nz)), P(_m1(zeta * w % R)), P(wzw))
+    return {"a": A, "b": B, "c": Cc, "z": Z, "tlo": TLO, "tmid": TMID, "thi": THI,
+            "wz": commit_m(wz), "wzw": commit_m(wzw), "ev": ev}
+
+
 def lin_scalars(key, public, beta, gamma, alpha, zeta, ev):
     """per-proof scalars of the linearisation polynomial
     r(X) = qm.qM + ql.qL + qr.qR + qo.qO + qC + s3.S3 + z.z(X) + tlo.t_lo + tmid.t_mid + thi.t_hi + r0"""

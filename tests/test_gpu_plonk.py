@@ -112,9 +112,8 @@ def test_smt_plonk_vs_oracle(zk_ctx):
 def test_config5_address_on_plonk_backend(zk_ctx):
     """BASELINE config 5 as it is worded: the secp256k1 address circuit (`ecdsa.DeriveAddress`,
     ecc/secp256k1/ecdsa/address.go:14-40) on the PLONK backend at full size: 231 270 gates, domain
-    2^18, quotient on 2^20.  The Python prover is too slow at this size, so the oracle side is
-    (i) the first-round commitments [a], [b], [c] recomputed from a CPU execution of the witness
-    program (Python inverse NTTs, C oracle MSM), bit for bit, (ii) the oracle's verifier and the
+    2^18, quotient on 2^20.  (i) two complete proofs -- nine commitments, six evaluations -- bit
+    for bit against the CPU oracle (its loops in C at this size), (ii) the oracle's verifier and the
     product's on the complete proofs, (iii) a wrong address flagged by the solver and rejected by
     the verifiers.  Parity unpinned with respect to gnark (address_test.go:57 proves with Groth16)."""
     from oracle import plonk_ref as P
@@ -135,10 +134,16 @@ def test_config5_address_on_plonk_backend(zk_ctx):
     prover.close()
     assert list(status != 0) == [False, False, True]
     n_pub = sc.n_public - 1
-    # (i) round 1 against the oracle
-    _, a, b, c = sc.run_vprogram(inps[1])
-    want = P.round1_commitments(pk.srs_g1, sc.log_n, a, b, c, blinds[1])
-    assert (proofs[1].a, proofs[1].b, proofs[1].c) == want
+    # (i) ALL nine commitments and six evaluations of two proofs against the oracle (the C twin of
+    # plonk_ref.prove, oracle/c/zkref_plonk.inc; tests/test_plonk.py pins it to the Python loops)
+    okey = P.setup_fast(sc, pk.srs_g1, pk.com, pk.g2_tau)
+    for i in (0, 1):
+        _, a, b, c = sc.run_vprogram(inps[i])
+        want = P.prove_fast(okey, a, b, c, inps[i][:n_pub], blinds[i])
+        assert _same(proofs[i], want), i
+        if i == 1:
+            assert P.round1_commitments(pk.srs_g1, sc.log_n, a, b, c, blinds[1]) == \
+                (want["a"], want["b"], want["c"])
     # (ii) complete proofs under both verifiers (the oracle's takes the verifying key as data)
     vkey = {"log_n": pk.log_n, "n_pub": n_pub, "com": pk.com, "g2_tau": pk.g2_tau}
     for i in (0, 1):

@@ -64,3 +64,31 @@ def test_plonk_oracle_proves_and_verifies():
     _, a, b, c = sc.run_vprogram(inp2)
     with pytest.raises(AssertionError):
         P.prove(key, a, b, c, inp2[:1], blind)
+
+
+def test_fast_oracle_prover_equals_the_python_loops():
+    """oracle/c/zkref_plonk.inc (grand product, quotient, evaluations, divisions in C) against the
+    plain-integer loops of plonk_ref.prove: same nine commitments and six evaluations, on the
+    Poseidon circuit and on the every-opcode circuit; an unsatisfied witness is refused."""
+    rng = random.Random(8)
+    sc = compile_scs(circuits.PoseidonCircuit())
+    key = P.setup(sc, 7)
+    for d in (12345, 0, R - 1):
+        inp = sc.assignment_vector({"Data": d, "Hash": poseidon_native.hash([d])})
+        _, a, b, c = sc.run_vprogram(inp)
+        pub = inp[:sc.n_public - 1]
+        blind = [rng.randrange(R) for _ in range(9)]
+        fast = P.prove_fast(key, a, b, c, pub, blind)
+        assert fast == P.prove(key, a, b, c, pub, blind)
+        assert P.verify(key, pub, fast)
+    inp2 = sc.assignment_vector({"Data": 1, "Hash": 5})
+    _, a, b, c = sc.run_vprogram(inp2)
+    with pytest.raises(AssertionError):
+        P.prove_fast(key, a, b, c, inp2[:1], blind)
+    sc = compile_scs(Mixed())
+    key = P.setup(sc, 9)
+    inp = sc.assignment_vector({"X": 77, "Y": 1234567, "Z": _mixed_expected(77, 1234567)})
+    _, a, b, c = sc.run_vprogram(inp)
+    pub = inp[:sc.n_public - 1]
+    blind = [rng.randrange(R) for _ in range(9)]
+    assert P.prove_fast(key, a, b, c, pub, blind) == P.prove(key, a, b, c, pub, blind)
