@@ -412,6 +412,28 @@ int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* d, zkmi_plonk_pk
   return ZKMI_OK;
 }
 
+// staging buffer of one round call: freed on every exit path, after the stream has drained
+struct RoundTmp {
+  zkmi_ctx* ctx;
+  void* p = nullptr;
+  explicit RoundTmp(zkmi_ctx* c) : ctx(c) {}
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      ctx->err = "plonk: hipMalloc(" + std::to_string(bytes) + " B) failed";
+      return ZKMI_ERR_OOM;
+    }
+    return ZKMI_OK;
+  }
+  ~RoundTmp() {
+    if (p) {
+      hipStreamSynchronize(ctx->stream);
+      hipFree(p);
+    }
+  }
+};
+
 // Round 1: witness solve (the constraint system's rows are the gate columns a, b, c), blinding,
 // commitments [a], [b], [c].
 int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const void* inputs,
@@ -442,25 +464,23 @@ int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const
     return rc;
   const size_t n_in = cs->n_public - 1 + cs->n_secret, nc = cs->n_constraints;
   // stage inputs + blinding scalars (host or device, proof-major)
-  void *in_dev = nullptr, *bl_dev = nullptr;
-  ZK_HIP(hipMalloc(&in_dev, batch * n_in * 32));
-  ZK_HIP(hipMalloc(&bl_dev, batch * 9 * 32));
-  ZK_HIP(hipMemcpyAsync(in_dev, inputs, batch * n_in * 32, hipMemcpyDefault, ctx->stream));
-  ZK_HIP(hipMemcpyAsync(bl_dev, blind, batch * 9 * 32, hipMemcpyDefault, ctx->stream));
-  // value file and gate columns: big[0] = slots (reused later), big[1..3] = a, b, c
-  if ((size_t)cs->n_slots > m) {
-    ctx->err = "plonk: value file larger than the 4n work buffer";
-    hipFree(in_dev);
-    hipFree(bl_dev);
+  // value file and gate columns: big[0] = slots (reused later), big[1..3] = a, b, c; every size is
+  // checked before anything is staged
+  if ((size_t)cs->n_slots > m || n_in > m) {
+    ctx->err = "plonk: value file or input vector larger than the 4n work buffer";
     return ZKMI_ERR_ARG;
   }
+  RoundTmp tin(ctx), tbl(ctx);
+  if ((rc = tin.alloc(batch * n_in * 32)) || (rc = tbl.alloc(batch * 9 * 32))) return rc;
+  void *in_dev = tin.p, *bl_dev = tbl.p;
+  ZK_HIP(hipMemcpyAsync(in_dev, inputs, batch * n_in * 32, hipMemcpyDefault, ctx->stream));
+  ZK_HIP(hipMemcpyAsync(bl_dev, blind, batch * 9 * 32, hipMemcpyDefault, ctx->stream));
   Fr* slots = (Fr*)pk->big[0].p;
   Fr *A = (Fr*)pk->big[1].p, *B = (Fr*)pk->big[2].p, *C = (Fr*)pk->big[3].p;
   void* st;
   if ((rc = ensure_scratch(ctx, 5, Bp * 4, &st))) return rc;
   rc = transpose_in(ctx, in_dev, slots + Bp, n_in, batch, Bp, 32);
   // the inputs in gnark's image, for PI(X) in round 3: big[5] rows 0 .. n_pub - 1 are the public ones
-  if (!rc && n_in > m) rc = ZKMI_ERR_ARG;
   if (!rc) rc = transpose_in(ctx, in_dev, pk->big[5].p, n_in, batch, Bp, 32);
   if (!rc) rc = rows_to_f_domain(ctx, slots + Bp, n_in, Bp);
   if (!rc) rc = transpose_in(ctx, bl_dev, pk->small[0].p, 9, batch, Bp, 32);
@@ -474,8 +494,6 @@ int zkmi_plonk_round1(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const
       hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 64), dim3(64), 0, ctx->stream,
                          col, nc, n, Bp);
   hipStreamSynchronize(ctx->stream);
-  hipFree(in_dev);
-  hipFree(bl_dev);
   if (rc) return rc;
   ZK_HIP(hipMemcpy(status_out, st, batch * 4, hipMemcpyDefault));
   NttPlan* plan;
@@ -523,13 +541,12 @@ int zkmi_plonk_round2(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* beta_gamma, 
   }
   const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
   int rc;
-  void* tmp;
-  ZK_HIP(hipMalloc(&tmp, batch * 64));
+  RoundTmp t2(ctx);
+  if ((rc = t2.alloc(batch * 64))) return rc;
+  void* tmp = t2.p;
   ZK_HIP(hipMemcpyAsync(tmp, beta_gamma, batch * 64, hipMemcpyDefault, ctx->stream));
   Fr* ch = (Fr*)pk->small[1].p;   // rows: 0 beta, 1 gamma, 2 alpha, 3 zeta ...
   rc = transpose_in(ctx, tmp, ch, 2, batch, Bp, 32);
-  hipStreamSynchronize(ctx->stream);
-  hipFree(tmp);
   if (rc) return rc;
   // the solver leaves rows >= n_constraints of the columns untouched: they must read as zero here
   Fr *A = (Fr*)pk->big[1].p, *B = (Fr*)pk->big[2].p, *C = (Fr*)pk->big[3].p;
@@ -570,13 +587,12 @@ int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void*
   }
   const size_t n = (size_t)1 << pk->log_n, m = 4 * n, Bp = pk->Bp, batch = pk->batch;
   int rc;
-  void* tmp;
-  ZK_HIP(hipMalloc(&tmp, batch * 32));
+  RoundTmp t3(ctx);
+  if ((rc = t3.alloc(batch * 32))) return rc;
+  void* tmp = t3.p;
   ZK_HIP(hipMemcpyAsync(tmp, alpha, batch * 32, hipMemcpyDefault, ctx->stream));
   Fr* ch = (Fr*)pk->small[1].p;
   rc = transpose_in(ctx, tmp, ch + 2 * Bp, 1, batch, Bp, 32);   // row 2
-  hipStreamSynchronize(ctx->stream);
-  hipFree(tmp);
   if (rc) return rc;
   NttPlan *plan_n, *plan_m;
   if ((rc = get_plan(ctx, (int)pk->log_n, &plan_n)) ||
@@ -623,16 +639,13 @@ int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, 
   }
   const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
   int rc;
-  void* tmp;
-  ZK_HIP(hipMalloc(&tmp, batch * 64));
+  RoundTmp t4(ctx), t4o(ctx);
+  if ((rc = t4.alloc(batch * 64)) || (rc = t4o.alloc(batch * 6 * 32))) return rc;
+  void* tmp = t4.p;
   ZK_HIP(hipMemcpyAsync(tmp, zeta_zetaw, batch * 64, hipMemcpyDefault, ctx->stream));
   Fr* pts = (Fr*)pk->small[1].p + 4 * Bp;   // rows 4, 5 of the challenge block: zeta, zeta w
   rc = transpose_in(ctx, tmp, pts, 2, batch, Bp, 32);
-  if (rc) {
-    hipStreamSynchronize(ctx->stream);
-    hipFree(tmp);
-    return rc;
-  }
+  if (rc) return rc;
   EvalArgs ea{};
   const Fr* polys[6] = {(Fr*)pk->cf[0].p, (Fr*)pk->cf[1].p, (Fr*)pk->cf[2].p, pk->coef + 5 * n,
                         pk->coef + 6 * n, (Fr*)pk->cf[3].p};
@@ -652,19 +665,12 @@ int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, 
   hipLaunchKernelGGL(plonk_eval_combine, dim3((unsigned)(Bp / 64), 6), dim3(64), 0, ctx->stream, ea,
                      (const Fr*)pts, (const Fr*)part, ev, n_chunks, Bp);
   ZK_HIP(hipGetLastError());
-  void* out_dev;
-  if (hipMalloc(&out_dev, batch * 6 * 32) != hipSuccess) {
-    hipStreamSynchronize(ctx->stream);
-    hipFree(tmp);
-    return ZKMI_ERR_OOM;
-  }
+  void* out_dev = t4o.p;
   rc = transpose_out(ctx, ev, out_dev, 6, batch, Bp, 32);
   if (!rc && hipMemcpyAsync(evals_out, out_dev, batch * 6 * 32, hipMemcpyDefault, ctx->stream) !=
                  hipSuccess)
     rc = ZKMI_ERR_HIP;
   hipStreamSynchronize(ctx->stream);
-  hipFree(tmp);
-  hipFree(out_dev);
   if (rc) return rc;
   pk->round = 4;
   return ZKMI_OK;
@@ -680,13 +686,12 @@ int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, voi
   }
   const size_t n = (size_t)1 << pk->log_n, Bp = pk->Bp, batch = pk->batch;
   int rc;
-  void* tmp;
-  ZK_HIP(hipMalloc(&tmp, batch * 14 * 32));
+  RoundTmp t5(ctx);
+  if ((rc = t5.alloc(batch * 14 * 32))) return rc;
+  void* tmp = t5.p;
   ZK_HIP(hipMemcpyAsync(tmp, scalars, batch * 14 * 32, hipMemcpyDefault, ctx->stream));
   Fr* sc = (Fr*)pk->small[0].p;
   rc = transpose_in(ctx, tmp, sc, 14, batch, Bp, 32);
-  hipStreamSynchronize(ctx->stream);
-  hipFree(tmp);
   if (rc) return rc;
   const size_t L = n + 3;
   // numerators in big[2], quotients in big[3]: 2 (n + 8) rows each (log_n >= 4)
