@@ -46,3 +46,24 @@ def rand_fr(rng, n, special=True):
 
 def rng(seed):
     return random.Random(seed)
+
+
+# ---- compiled circuits shared by the full-size GPU tests (compile once per session: Arbo-160 is 8 s,
+# the address circuit 7 s, its SCS lowering 17 s)
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def compiled(name):
+    from gnark_crypto_primitives_amd import circuits
+    from gnark_crypto_primitives_amd.frontend import compile_circuit
+    if name == "arbo160":
+        return compile_circuit(circuits.smt_inclusion_circuit(160))
+    if name == "address":
+        return compile_circuit(circuits.AddressCircuit())
+    if name == "address-commit":
+        return compile_circuit(circuits.AddressCircuitCommit())
+    if name == "address-scs":
+        from gnark_crypto_primitives_amd.frontend.scs import compile_scs
+        return compile_scs(compiled("address"))
+    raise KeyError(name)

@@ -47,7 +47,7 @@ def test_arbo160_auto_plan_pipelined_vs_oracle(zk_ctx):
     between lanes: the tables stream from HBM), auto plan; a 64-proof sample of every batch is
     compared bit for bit with the C oracle's Groth16 prover."""
     from oracle import cref
-    cc = compile_circuit(circuits.smt_inclusion_circuit(160))
+    cc = H.compiled("arbo160")
     pk, vk, td = groth16.setup(cc, 2, groth16.gpu_mul(zk_ctx))
     prover = groth16.Prover(zk_ctx, cc, pk, 0, 0)
     info = zk_ctx.pk_info(prover.pk_h)
@@ -63,8 +63,10 @@ def test_arbo160_auto_plan_pipelined_vs_oracle(zk_ctx):
             for k, ((inp, rs, bad), (proofs, status)) in enumerate(zip(batches, got)):
                 assert list(np.nonzero(status)[0]) == [bad], (populated, k)
                 assert status[bad] == -5
-                sample = sorted(set(EDGE + [bad - 1, bad + 1] +
-                                    [rng.randrange(B) for _ in range(64)]) - {bad})[:64]
+                # 64 lanes of the first batch of each kind, 32 of the two behind it in the pipeline
+                lanes = sorted(set(EDGE + [bad - 1, bad + 1]) - {bad})
+                lanes += [x for x in (rng.randrange(B) for _ in range(200)) if x != bad and x not in lanes]
+                sample = sorted(lanes[:64 if k == 0 else 32])
                 want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp[sample], rs[sample], 16)
                 assert not wstatus.any()
                 assert np.array_equal(proofs[sample], want), (populated, k)

@@ -93,7 +93,7 @@ def test_config5_address_with_commitment_range_checks(zk_ctx):
     R1CS builder (lookup + commitment, 144 committed wires), 2^18 domain, auto plan."""
     from gnark_crypto_primitives_amd.std.emulated import limbs_of
     from oracle import pyref
-    cc = compile_circuit(circuits.AddressCircuitCommit())
+    cc = H.compiled("address-commit")
     assert cc.domain_log2() == 18 and len(cc.commitments) == 1
     assert len(cc.commitments[0]["private"]) == 144           # 128 nibbles + 16 multiplicities
     rng = random.Random(56)

@@ -82,7 +82,7 @@ def test_arbo160_prove_vs_oracle(zk_ctx):
     """The headline circuit itself (160 levels, 40 361 constraints, domain 2^16), 5 proofs,
     bit-exact against the C oracle; narrower windows than the bench to keep the tables small."""
     from oracle import cref
-    cc = compile_circuit(circuits.smt_inclusion_circuit(160))
+    cc = H.compiled("arbo160")
     assert cc.n_constraints == 40361 and cc.domain_log2() == 16
     pk, vk, td = groth16.setup(cc, 2, groth16.gpu_mul(zk_ctx))
     prover = groth16.Prover(zk_ctx, cc, pk, 6, 5)

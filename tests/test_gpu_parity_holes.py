@@ -120,7 +120,7 @@ def test_config4_elgamal_add_8192(zk_ctx):
     pk, _, _ = groth16.setup(cc, 4, groth16.gpu_mul(zk_ctx))
     prover = groth16.Prover(zk_ctx, cc, pk, 0, 0, max_batch=B)
     rng = random.Random(404)
-    distinct = [to_mont_array(cc.assignment_vector(gen(rng))) for _ in range(96)]
+    distinct = [to_mont_array(cc.assignment_vector(gen(rng))) for _ in range(20)]   # 0.3 s each (Python curve arithmetic)
     try:
         order = [rng.randrange(len(distinct)) for _ in range(B)]
         inp = np.stack([distinct[i] for i in order])
@@ -142,7 +142,7 @@ def test_two_arbo160_keys_share_one_gpu_at_64gb_each(zk_ctx):
     table_budget_bytes = 64 GB each live on one context and both prove oracle-exact samples."""
     from oracle import cref
     B = 1024
-    cc = compile_circuit(circuits.smt_inclusion_circuit(160))
+    cc = H.compiled("arbo160")
     rng = random.Random(64)
     ws = [to_mont_array(cc.assignment_vector(smt_witness.synthetic_inclusion(rng, 160, 1 + i % 159)))
           for i in range(128)]
@@ -162,7 +162,7 @@ def test_two_arbo160_keys_share_one_gpu_at_64gb_each(zk_ctx):
             p.submit(inp, rs)
             proofs, status = p.collect()
             assert not status.any()
-            sample = _sample(rng, B)
+            sample = _sample(rng, B)[::2]                      # 32 lanes per key
             want, wstatus, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk),
                                                         inp[sample], rs[sample], 16)
             assert not wstatus.any() and np.array_equal(proofs[sample], want), k

@@ -118,8 +118,9 @@ def test_config5_address_on_plonk_backend(zk_ctx):
     the verifiers.  Parity unpinned with respect to gnark (address_test.go:57 proves with Groth16)."""
     from oracle import plonk_ref as P
     from gnark_crypto_primitives_amd import workloads
-    circuit, gen, _ = workloads.build("address")
-    sc = compile_scs(circuit)
+    from tests import helpers as H
+    _, gen, _ = workloads.build("address")
+    sc = H.compiled("address-scs")
     assert sc.log_n == 18 and sc.n_gates > 200_000
     pk = plonk.setup(zk_ctx, sc, 11)
     prover = plonk.Prover(zk_ctx, sc, pk, max_batch=64)

@@ -156,10 +156,10 @@ def test_pipelined_submit_collect_matches_blocking(zk_ctx, poseidon_setup):
     prover.collect()
 
 
-def _prove_and_check(zk_ctx, cc, assignments, seed, wbits=(7, 5), info_out=None, **plan):
+def _prove_and_check(zk_ctx, cc, assignments, seed, wbits=(7, 5), info_out=None, keys=None, **plan):
     """prove a batch on the GPU and compare every proof with the C oracle."""
     from oracle import cref
-    pk, vk, td = groth16.setup(cc, seed, groth16.gpu_mul(zk_ctx))
+    pk, vk, td = keys if keys is not None else groth16.setup(cc, seed, groth16.gpu_mul(zk_ctx))
     prover = groth16.Prover(zk_ctx, cc, pk, *wbits, **plan)
     if info_out is not None:
         info_out.update(zk_ctx.pk_info(prover.pk_h))
@@ -270,7 +270,7 @@ def test_config5_secp256k1_address(zk_ctx):
     address taken from the Python oracle (public vectors for keys 1 and 2)."""
     from gnark_crypto_primitives_amd.std.emulated import limbs_of
     from oracle import pyref
-    cc = compile_circuit(circuits.AddressCircuit())
+    cc = H.compiled("address")
     assert cc.domain_log2() == 18
     rng = random.Random(55)
     asg = []
@@ -280,13 +280,15 @@ def test_config5_secp256k1_address(zk_ctx):
                     "Y": limbs_of(pub[1])})
     assert asg[0]["Address"] == 0x7E5F4552091A69125D5DFCB7B8C2659029395BDF
     asg[3] = dict(asg[3], Address=asg[2]["Address"])      # someone else's address -> unsatisfied
-    status = _prove_and_check(zk_ctx, cc, asg, 5, wbits=(5, 4))
+    keys = groth16.setup(cc, 5, groth16.gpu_mul(zk_ctx))      # one setup for both table plans
+    status = _prove_and_check(zk_ctx, cc, asg, 5, wbits=(5, 4), keys=keys)
     assert list(status != 0) == [False, False, False, True]
     # the auto plan of a witness of bits (zkmi_pk_desc.sparse_witness = 2, what bench.py runs): small
     # subset-sum tables for the wire MSMs, the dense quotient MSM on its own sign-pattern tables
     assert cc.n_boolean_wires * 100 >= cc.n_wires * 99
     info = {}
-    status = _prove_and_check(zk_ctx, cc, asg, 6, wbits=(0, 0), info_out=info, max_batch=64)
+    status = _prove_and_check(zk_ctx, cc, asg, 6, wbits=(0, 0), info_out=info, keys=keys,
+                              max_batch=64)
     assert list(status != 0) == [False, False, False, True]
     assert info["g2_comb_k"] == 12 and info["g2_windows"] == 254, info      # wires: subset sums
     assert info["g1_comb_k"] >= 16 and info["g1_windows"] == 255, info      # quotient: sign patterns

@@ -130,7 +130,7 @@ def test_arbo160_witness_entry_full_size_from_host(zk_ctx):
     equals zkmi_prove_batch on the same inputs."""
     from oracle import cref
     B = 1024
-    cc = compile_circuit(circuits.smt_inclusion_circuit(160))
+    cc = H.compiled("arbo160")
     pk, vk, td = groth16.setup(cc, 2, groth16.gpu_mul(zk_ctx))
     prover = groth16.Prover(zk_ctx, cc, pk, 0, 0)
     info = zk_ctx.pk_info(prover.pk_h)
@@ -166,8 +166,9 @@ def test_arbo160_witness_entry_full_size_from_host(zk_ctx):
         for k, ((inp, rs, W, abc, full), (proofs, status)) in enumerate(zip(batches, got)):
             assert not status.any(), k
             assert np.array_equal(proofs, full), k
-            sample = sorted(set([0, 1, 63, 64, 65, 511, 512, 1022, 1023] +
-                                [rng.randrange(B) for _ in range(64)]))[:64]
+            lanes = [0, 1, 63, 64, 65, 511, 512, 1022, 1023]
+            lanes += [x for x in (rng.randrange(B) for _ in range(200)) if x not in lanes]
+            sample = sorted(lanes[:64 if k in (0, 3) else 24])      # k = 3: the W + a + b + c form
             want, wstatus, _ = cref.groth16_prove_batch(rh, ph, inp[sample], rs[sample], 16)
             assert not wstatus.any()
             assert np.array_equal(proofs[sample], want), k
