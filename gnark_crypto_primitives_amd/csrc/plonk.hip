@@ -16,6 +16,8 @@
 #include <algorithm>
 
 #include "zkmi_internal.h"
+#include "sha256.h"
+#include <cstring>
 
 using namespace zk;
 
@@ -129,15 +131,27 @@ __global__ __launch_bounds__(64) void plonk_quotient(const Fr* ea, const Fr* eb,
                                                      const Fr* ez, const Fr* epi, const Fr* ks,
                                                      const Fr* xs, const Fr* l1, const Fr* zh_inv,
                                                      const Fr* ch, Fr* T, size_t m, size_t Bp,
-                                                     Fr k1, Fr k2) {
+                                                     Fr k1, Fr k2, int n_pub_direct) {
   LANE;
   const Fr beta = bi_ld(ch, 0, lane, Bp), gamma = bi_ld(ch, 1, lane, Bp),
            alpha = bi_ld(ch, 2, lane, Bp);
+  // n_pub_direct >= 0: `epi` holds the public inputs x_t themselves (rows 0 .. n_pub - 1) and PI on
+  // the coset is evaluated in closed form: L_t(x) = L_0(x / w^t) and x_j / w^t = x_(j - 4t) on the
+  // coset 5 <w_4n>, so PI(x_j) = - sum_t x_t L1[j - 4t] -- no transform for a handful of inputs
+  Fr pub[8];
+  for (int t = 0; t < 8; t++) pub[t] = t < n_pub_direct ? bi_ld(epi, t, lane, Bp) : Fr::zero();
   for (size_t j = blockIdx.y; j < m; j += gridDim.y) {
     const Fr a = bi_ld(ea, j, lane, Bp), b = bi_ld(eb, j, lane, Bp), c = bi_ld(ec, j, lane, Bp),
              z = bi_ld(ez, j, lane, Bp), zw = bi_ld(ez, (j + 4) & (m - 1), lane, Bp);
     Fr gate = add(add(mul(ks[j], a), mul(ks[m + j], b)), mul(ks[2 * m + j], c));
-    gate = add(add(gate, mul(ks[3 * m + j], mul(a, b))), add(ks[4 * m + j], bi_ld(epi, j, lane, Bp)));
+    Fr pi;
+    if (n_pub_direct >= 0) {
+      pi = Fr::zero();
+      for (int t = 0; t < n_pub_direct; t++) pi = sub(pi, mul(pub[t], l1[(j - 4 * (size_t)t) & (m - 1)]));
+    } else {
+      pi = bi_ld(epi, j, lane, Bp);
+    }
+    gate = add(add(gate, mul(ks[3 * m + j], mul(a, b))), add(ks[4 * m + j], pi));
     const Fr bx = mul(beta, xs[j]);
     const Fr ag = add(a, gamma), bg = add(b, gamma), cg = add(c, gamma);
     const Fr p1 = mul(mul(mul(add(ag, bx), add(bg, mul(bx, k1))), add(cg, mul(bx, k2))), z);
@@ -600,17 +614,22 @@ int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void*
     return rc;
   // PI(X): Lagrange values (-x_j) from the public-input rows saved in big[5] -> coefficients
   // (big[0]) -> coset evaluations (big[5])
-  Fr* pil = (Fr*)pk->big[0].p;
-  hipLaunchKernelGGL(plonk_pi, dim3((unsigned)(Bp / 64), (unsigned)(n < 4096 ? n : 4096)),
-                     dim3(64), 0, ctx->stream, (const Fr*)pk->big[5].p, pil, (size_t)pk->n_public, n,
-                     Bp);
-  ZK_HIP(hipGetLastError());
-  Fr* pic = pil + n * Bp;
-  if ((rc = ntt_bi(ctx, plan_n, pil, pic, Bp, true, false, n))) return rc;
+  // (circuits with more than eight public inputs; otherwise plonk_quotient evaluates PI itself)
+  const int n_pub_direct = pk->n_public <= 8 ? (int)pk->n_public : -1;
   Fr *EA = (Fr*)pk->big[1].p, *EB = (Fr*)pk->big[2].p, *EC = (Fr*)pk->big[3].p,
      *EZ = (Fr*)pk->big[4].p, *EPI = (Fr*)pk->big[5].p;
-  if ((rc = ntt_bi(ctx, plan_m, pic, EPI, Bp, false, true, n)) ||
-      (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[0].p, EA, Bp, false, true, n + 2)) ||
+  if (n_pub_direct < 0) {
+    Fr* pil = (Fr*)pk->big[0].p;
+    hipLaunchKernelGGL(plonk_pi, dim3((unsigned)(Bp / 64), (unsigned)(n < 4096 ? n : 4096)),
+                       dim3(64), 0, ctx->stream, (const Fr*)pk->big[5].p, pil, (size_t)pk->n_public, n,
+                       Bp);
+    ZK_HIP(hipGetLastError());
+    Fr* pic = pil + n * Bp;
+    if ((rc = ntt_bi(ctx, plan_n, pil, pic, Bp, true, false, n)) ||
+        (rc = ntt_bi(ctx, plan_m, pic, EPI, Bp, false, true, n)))
+      return rc;
+  }
+  if ((rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[0].p, EA, Bp, false, true, n + 2)) ||
       (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[1].p, EB, Bp, false, true, n + 2)) ||
       (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[2].p, EC, Bp, false, true, n + 2)) ||
       (rc = ntt_bi(ctx, plan_m, (Fr*)pk->cf[3].p, EZ, Bp, false, true, n + 3)))
@@ -618,7 +637,7 @@ int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void*
   Fr* T = (Fr*)pk->big[0].p;
   hipLaunchKernelGGL(plonk_quotient, dim3((unsigned)(Bp / 64), (unsigned)(m < 8192 ? m : 8192)),
                      dim3(64), 0, ctx->stream, EA, EB, EC, EZ, EPI, pk->coset, pk->coset_x, pk->l1,
-                     pk->zh_inv, ch, T, m, Bp, fr_small(5), fr_small(25));
+                     pk->zh_inv, ch, T, m, Bp, fr_small(5), fr_small(25), n_pub_direct);
   ZK_HIP(hipGetLastError());
   // coset interpolation: t coefficients in big[1]
   Fr* ct = (Fr*)pk->big[1].p;
@@ -730,6 +749,219 @@ int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, voi
   const Fr* scs[2] = {W, WZ};
   if ((rc = commit(ctx, pk, 2, scs, nullptr, commits_w_out, batch))) return rc;
   pk->round = 0;
+  return ZKMI_OK;
+}
+
+}  // extern "C"
+
+// ---- plonk.Prove in one call: the five rounds with the Fiat-Shamir transcript on the host in C++ --------
+// Transcript (the Python twin is plonk.py::challenge / lin_scalars): SHA-256(label ||
+// parts) mod r, integers as 32 big-endian bytes, G1 points as x || y big-endian (infinity: 64 zero
+// bytes).  gamma = H("gamma", vk digest, public inputs, [a], [b], [c]); beta = H("beta", gamma);
+// alpha = H("alpha", beta, [z]); zeta = H("zeta", alpha, [t_lo], [t_mid], [t_hi]);
+// v = H("v", zeta, six evaluations).
+namespace {
+void fr_be(uint8_t out[32], const Fr& plain) {
+  for (int i = 0; i < 8; i++) {
+    const uint32_t x = plain.v[7 - i];
+    out[4 * i] = (uint8_t)(x >> 24);
+    out[4 * i + 1] = (uint8_t)(x >> 16);
+    out[4 * i + 2] = (uint8_t)(x >> 8);
+    out[4 * i + 3] = (uint8_t)x;
+  }
+}
+struct Transcript {
+  Sha256 h;
+  explicit Transcript(const char* label) { h.update((const uint8_t*)label, strlen(label)); }
+  void fr_mont(const Fr& m) {   // a field element given in Montgomery form
+    uint8_t b[32];
+    fr_be(b, from_mont(m));
+    h.update(b, 32);
+  }
+  void point(const G1Affine& p) {
+    uint8_t b[64] = {0};
+    if (!(p.x.is_zero() && p.y.is_zero())) {
+      const Fq x = from_mont(p.x), y = from_mont(p.y);
+      for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 4; k++) {
+          b[4 * i + k] = (uint8_t)(x.v[7 - i] >> (24 - 8 * k));
+          b[32 + 4 * i + k] = (uint8_t)(y.v[7 - i] >> (24 - 8 * k));
+        }
+    }
+    h.update(b, 64);
+  }
+  Fr challenge() {   // digest as a big-endian integer, reduced mod r, in Montgomery form
+    uint8_t d[32];
+    h.final(d);
+    Fr x = Fr::zero();
+    for (int i = 0; i < 32; i++) x.v[7 - i / 4] |= (uint32_t)d[i] << (24 - 8 * (i % 4));
+    for (;;) {
+      bool ge = true;
+      for (int j = 7; j >= 0; j--)
+        if (x.v[j] != FrParams::p(j)) {
+          ge = x.v[j] > FrParams::p(j);
+          break;
+        }
+      if (!ge) break;
+      int64_t br = 0;
+      for (int j = 0; j < 8; j++) {
+        const int64_t t = (int64_t)x.v[j] - (int64_t)FrParams::p(j) + br;
+        x.v[j] = (uint32_t)t;
+        br = t >> 32;
+      }
+    }
+    return to_mont(x);
+  }
+};
+Fr fr_pow_u64(Fr base, uint64_t e) {
+  Fr r = Fr::one();
+  while (e) {
+    if (e & 1) r = mul(r, base);
+    base = sqr(base);
+    e >>= 1;
+  }
+  return r;
+}
+Fr fr_u64(uint64_t v) {
+  Fr x = Fr::zero();
+  x.v[0] = (uint32_t)v;
+  x.v[1] = (uint32_t)(v >> 32);
+  return to_mont(x);
+}
+}  // namespace
+
+extern "C" {
+
+/* proofs_out: batch x 96 words of 8 bytes = 9 G1 affine points ([a] [b] [c] [z] [t_lo] [t_mid] [t_hi]
+ * [W_zeta] [W_zeta_w], Montgomery) then 6 fr (a, b, c, S1, S2 at zeta, z at zeta w; Montgomery). */
+int zkmi_plonk_prove(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const void* inputs,
+                     size_t batch, const void* blind, const uint8_t* vk_digest /* 32 bytes */,
+                     void* proofs_out, int32_t* status_out) {
+  if (!ctx || !pk || !cs || !inputs || !blind || !vk_digest || !proofs_out || !status_out || batch == 0)
+    return ZKMI_ERR_ARG;
+  const size_t n = (size_t)1 << pk->log_n, n_pub = pk->n_public;
+  const size_t n_in = cs->n_public - 1 + cs->n_secret;
+  // public inputs on the host (gnark's image)
+  std::vector<Fr> pubs(batch * (n_pub ? n_pub : 1));
+  for (size_t p = 0; p < batch && n_pub; p++)
+    if (hipMemcpy(pubs.data() + p * n_pub, (const char*)inputs + p * n_in * 32, n_pub * 32,
+                  hipMemcpyDefault) != hipSuccess) {
+      ctx->err = "plonk_prove: cannot read the public inputs";
+      return ZKMI_ERR_HIP;
+    }
+  std::vector<G1Affine> abc(batch * 3), cz(batch), ct(batch * 3), cw(batch * 2);
+  std::vector<Fr> bg(batch * 2), al(batch), zz(batch * 2), ev(batch * 6), sc(batch * 14);
+  int rc = zkmi_plonk_round1(ctx, pk, cs, inputs, batch, blind, abc.data(), status_out);
+  if (rc) return rc;
+  for (size_t p = 0; p < batch; p++) {
+    Transcript t("gamma");
+    t.h.update(vk_digest, 32);
+    for (size_t j = 0; j < n_pub; j++) t.fr_mont(pubs[p * n_pub + j]);
+    for (int k = 0; k < 3; k++) t.point(abc[p * 3 + k]);
+    const Fr gamma = t.challenge();
+    Transcript tb("beta");
+    tb.fr_mont(gamma);
+    bg[2 * p] = tb.challenge();
+    bg[2 * p + 1] = gamma;
+  }
+  if ((rc = zkmi_plonk_round2(ctx, pk, bg.data(), cz.data()))) return rc;
+  for (size_t p = 0; p < batch; p++) {
+    Transcript t("alpha");
+    t.fr_mont(bg[2 * p]);
+    t.point(cz[p]);
+    al[p] = t.challenge();
+  }
+  if ((rc = zkmi_plonk_round3(ctx, pk, al.data(), ct.data()))) return rc;
+  // w = 5^((r - 1) / n): root of unity of the domain, from the key's omega table
+  Fr w;
+  if (hipMemcpy(&w, pk->omega + 1, 32, hipMemcpyDefault) != hipSuccess) return ZKMI_ERR_HIP;
+  for (size_t p = 0; p < batch; p++) {
+    Transcript t("zeta");
+    t.fr_mont(al[p]);
+    for (int k = 0; k < 3; k++) t.point(ct[p * 3 + k]);
+    zz[2 * p] = t.challenge();
+    zz[2 * p + 1] = mul(zz[2 * p], w);
+  }
+  if ((rc = zkmi_plonk_round4(ctx, pk, zz.data(), ev.data()))) return rc;
+  const Fr ninv = inverse(fr_u64(n)), five = fr_u64(5), tf = fr_u64(25);
+  // 1 / (zeta - w^j), j = 0 .. max(n_pub, 1) - 1 (j = 0 also serves L_1), for every proof: one
+  // inversion in all (Montgomery's trick); zeta = w^j has probability 2^-250
+  const size_t nd = n_pub ? n_pub : 1;
+  std::vector<Fr> den(batch * nd), pre(batch * nd);
+  {
+    Fr acc = Fr::one();
+    for (size_t p = 0; p < batch; p++) {
+      Fr wj = Fr::one();
+      for (size_t j = 0; j < nd; j++) {
+        den[p * nd + j] = sub(zz[2 * p], wj);
+        pre[p * nd + j] = acc;
+        if (!den[p * nd + j].is_zero()) acc = mul(acc, den[p * nd + j]);
+        wj = mul(wj, w);
+      }
+    }
+    Fr inv = inverse(acc);
+    for (size_t i = batch * nd; i-- > 0;) {
+      if (den[i].is_zero()) continue;
+      const Fr t = mul(inv, pre[i]);
+      inv = mul(inv, den[i]);
+      den[i] = t;
+    }
+  }
+  for (size_t p = 0; p < batch; p++) {
+    const Fr beta = bg[2 * p], gamma = bg[2 * p + 1], alpha = al[p], zeta = zz[2 * p];
+    const Fr* e = ev.data() + 6 * p;   // a, b, c, s1, s2, z(zeta w)
+    Transcript t("v");
+    t.fr_mont(zeta);
+    for (int k = 0; k < 6; k++) t.fr_mont(e[k]);
+    const Fr v = t.challenge();
+    // scalars of the linearisation polynomial (plonk.py::lin_scalars)
+    const Fr zh = sub(fr_pow_u64(zeta, n), Fr::one());
+    const Fr l1 = mul(mul(zh, ninv), den[p * nd]);
+    Fr pi = Fr::zero(), wj = Fr::one();
+    for (size_t j = 0; j < n_pub; j++) {   // PI(zeta) = sum_j -x_j L_j(zeta)
+      const Fr lj = mul(mul(mul(zh, wj), ninv), den[p * nd + j]);
+      pi = sub(pi, mul(pubs[p * n_pub + j], lj));
+      wj = mul(wj, w);
+    }
+    const Fr bz = mul(beta, zeta);
+    const Fr a1 = mul(mul(add(add(e[0], bz), gamma), add(add(e[1], mul(five, bz)), gamma)),
+                      add(add(e[2], mul(tf, bz)), gamma));
+    const Fr a2 = mul(add(add(e[0], mul(beta, e[3])), gamma), add(add(e[1], mul(beta, e[4])), gamma));
+    const Fr zn2 = fr_pow_u64(zeta, n + 2), al2 = mul(alpha, alpha);
+    Fr* s = sc.data() + 14 * p;
+    s[0] = mul(e[0], e[1]);                                        // qm
+    s[1] = e[0];                                                   // ql
+    s[2] = e[1];                                                   // qr
+    s[3] = e[2];                                                   // qo
+    s[4] = neg(mul(mul(mul(alpha, a2), beta), e[5]));              // s3
+    s[5] = add(mul(alpha, a1), mul(al2, l1));                      // z
+    s[6] = neg(zh);                                                // t_lo
+    s[7] = neg(mul(zh, zn2));                                      // t_mid
+    s[8] = neg(mul(mul(zh, zn2), zn2));                            // t_hi
+    Fr c0 = sub(sub(pi, mul(al2, l1)), mul(mul(mul(alpha, a2), add(e[2], gamma)), e[5]));   // r0
+    Fr vp = Fr::one();
+    for (int k = 0; k < 5; k++) {
+      vp = mul(vp, v);
+      c0 = sub(c0, mul(vp, e[k]));
+    }
+    s[9] = c0;
+    s[10] = v;
+    s[11] = zeta;
+    s[12] = zz[2 * p + 1];
+    s[13] = e[5];
+  }
+  if ((rc = zkmi_plonk_round5(ctx, pk, sc.data(), cw.data()))) return rc;
+  // assemble the records on the host, one copy out (host or device destination)
+  std::vector<uint8_t> rec(batch * 768);
+  for (size_t p = 0; p < batch; p++) {
+    uint8_t* r = rec.data() + p * 768;
+    memcpy(r, &abc[p * 3], 192);
+    memcpy(r + 192, &cz[p], 64);
+    memcpy(r + 256, &ct[p * 3], 192);
+    memcpy(r + 448, &cw[p * 2], 128);
+    memcpy(r + 576, &ev[p * 6], 192);
+  }
+  ZK_HIP(hipMemcpy(proofs_out, rec.data(), rec.size(), hipMemcpyDefault));
   return ZKMI_OK;
 }
 

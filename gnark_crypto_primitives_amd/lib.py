@@ -95,6 +95,7 @@ SYMBOLS = [
     ("zkmi_plonk_round3", _I, [_P, _P, _P, _P]),
     ("zkmi_plonk_round4", _I, [_P, _P, _P, _P]),
     ("zkmi_plonk_round5", _I, [_P, _P, _P, _P]),
+    ("zkmi_plonk_prove", _I, [_P, _P, _P, _P, _SZ, _P, _P, _P, _P]),
 ]
 
 _lib = None

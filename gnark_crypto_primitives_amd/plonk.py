@@ -299,9 +299,40 @@ class Prover:
             self.ctx.cs_free(self.cs_h)
             self.cs_h = None
 
+    def prove_raw(self, inputs, blind):
+        """plonk.Prove through zkmi_plonk_prove: the five rounds with the transcript hashed in C++
+        inside the library (no Python between the rounds).  Returns (records uint64 [batch, 96]: nine
+        G1 points then six evaluations, gnark's Montgomery image; status [batch]); ``proofs_of``
+        turns records into Proof values."""
+        batch = inputs.shape[0]
+        if tuple(inputs.shape) != (batch, self.scs.n_inputs, 4) or tuple(blind.shape) != (batch, 9, 4):
+            raise ValueError("inputs must be [batch, n_inputs, 4], blind [batch, 9, 4]")
+        inputs, blind = np.ascontiguousarray(inputs), np.ascontiguousarray(blind)
+        rec = np.zeros((batch, 96), dtype=np.uint64)
+        status = np.zeros(batch, dtype=np.int32)
+        vkd = (C.c_uint8 * 32).from_buffer_copy(self.pk.vk_digest)
+        self.ctx._check(self.ctx.lib.zkmi_plonk_prove(self.ctx.h, self.pk_h, self.cs_h,
+                                                      inputs.ctypes.data, batch, blind.ctypes.data,
+                                                      vkd, rec.ctypes.data, status.ctypes.data),
+                        "zkmi_plonk_prove")
+        return rec, status
+
+    @staticmethod
+    def proofs_of(rec):
+        """records of prove_raw -> list of Proof"""
+        rinv = pow(1 << 256, R - 2, R)
+        out = []
+        for r in np.ascontiguousarray(rec, dtype=np.uint64).reshape(-1, 96):
+            pts = [_verify.g1_from_image(r[8 * k:8 * k + 8]) for k in range(9)]
+            ev = tuple(v * rinv % R for v in array_to_ints(r[72:96].reshape(6, 4)))
+            out.append(Proof(**dict(zip(Proof.FIELDS, pts)), ev=ev))
+        return out
+
     def prove(self, inputs, blind):
         """inputs: [batch, n_inputs, 4] Montgomery (public first); blind: [batch, 9, 4] Montgomery.
-        Returns (list of Proof, status [batch])."""
+        Returns (list of Proof, status [batch]).  The five rounds one by one with the transcript in
+        Python: the reference implementation of the transcript that ``prove_raw`` (C++) is tested
+        against."""
         ctx, lib, pk = self.ctx, self.ctx.lib, self.pk
         batch = inputs.shape[0]
         if tuple(inputs.shape) != (batch, self.scs.n_inputs, 4) or tuple(blind.shape) != (batch, 9, 4):

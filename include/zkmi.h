@@ -354,6 +354,15 @@ int zkmi_plonk_round4(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* zeta_zetaw, 
  * commits_w_out: batch x 2 G1 ([W_zeta] [W_zeta_w]). */
 int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, void* commits_w_out);
 
+/* plonk.Prove for a batch in one call: the five rounds above with the Fiat-Shamir transcript (SHA-256,
+ * DESIGN.md §3.6) computed on the host inside the library between them.  vk_digest: the 32-byte
+ * digest of the verifying key that opens the transcript (plonk.py: ProvingKey.vk_digest).
+ *   proofs_out: batch x 768 bytes: 9 G1 affine points ([a] [b] [c] [z] [t_lo] [t_mid] [t_hi]
+ *   [W_zeta] [W_zeta_w]) then 6 fr (a, b, c, S1, S2 at zeta, z at zeta w), gnark's Montgomery image. */
+int zkmi_plonk_prove(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const zkmi_cs* cs, const void* inputs,
+                     size_t batch, const void* blind, const uint8_t* vk_digest, void* proofs_out,
+                     int32_t* status_out);
+
 /* Per-stage device time of the last zkmi_prove_collect / zkmi_prove_batch in milliseconds, from
  * HIP events on the library's streams: [0] solve (stage 1, second stream), [1] quotient (NTTs +
  * pointwise), [2] G1 MSMs, [3] G2 MSM, [4] assembly (third stream; overlaps the next batch's

@@ -155,3 +155,37 @@ def test_config5_address_on_plonk_backend(zk_ctx):
     # (iii) the wrong address: neither its own public inputs nor the right ones make it verify
     assert not plonk.verify(pk, inps[2][:n_pub], proofs[2])
     assert not plonk.verify(pk, inps[1][:n_pub], proofs[0])
+
+
+def test_plonk_prove_in_one_call_equals_the_round_by_round_prover(zk_ctx):
+    """zkmi_plonk_prove (transcript hashed in C++ between the rounds) against plonk.Prover.prove (the
+    same rounds driven from Python with the Python transcript): identical proofs, on the Poseidon
+    circuit (one public input) and on a circuit with three public inputs."""
+    from tests.test_frontend import Mixed, _mixed_expected
+    rng = random.Random(17)
+    sc = compile_scs(circuits.PoseidonCircuit())
+    pk = plonk.setup(zk_ctx, sc, 7)
+    prover = plonk.Prover(zk_ctx, sc, pk, max_batch=128)
+    datas = [rng.randrange(R) for _ in range(70)]
+    inps = [sc.assignment_vector({"Data": d, "Hash": poseidon_native.hash([d])}) for d in datas]
+    inps[5] = sc.assignment_vector({"Data": 1, "Hash": 2})
+    inp = np.stack([to_mont_array(v) for v in inps])
+    blind = np.stack([to_mont_array([rng.randrange(R) for _ in range(9)]) for _ in inps])
+    want, wstatus = prover.prove(inp, blind)
+    rec, status = prover.prove_raw(inp, blind)
+    got = prover.proofs_of(rec)
+    prover.close()
+    assert np.array_equal(status, wstatus) and list(np.nonzero(status)[0]) == [5]
+    assert all(got[i] == want[i] for i in range(70) if i != 5)
+    assert plonk.verify(pk, inps[0][:1], got[0])
+    sc = compile_scs(Mixed())
+    pk = plonk.setup(zk_ctx, sc, 8)
+    prover = plonk.Prover(zk_ctx, sc, pk, max_batch=64)
+    asg = [(7 + i, 1000 + 3 * i) for i in range(5)]
+    inps = [sc.assignment_vector({"X": x, "Y": y, "Z": _mixed_expected(x, y)}) for x, y in asg]
+    inp = np.stack([to_mont_array(v) for v in inps])
+    blind = np.stack([to_mont_array([rng.randrange(R) for _ in range(9)]) for _ in inps])
+    want, _ = prover.prove(inp, blind)
+    got = prover.proofs_of(prover.prove_raw(inp, blind)[0])
+    prover.close()
+    assert got == want and plonk.verify(pk, inps[2][:sc.n_public - 1], got[2])
