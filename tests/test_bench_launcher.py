@@ -65,3 +65,25 @@ def test_launcher_reports_a_failing_rank(tmp_path):
     assert r.returncode == 7
     assert r.stdout.strip() == "rank 0"             # only rank 0's stdout is forwarded
     assert "rank 1 exited with 7" in r.stderr
+
+
+def test_under_torch_distributed_run_as_the_driver_launches_it(tmp_path):
+    """The driver's N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...  Each process is then one rank
+    (RANK / WORLD_SIZE inherited); rank 0 prints the one JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, ZKMI_CACHE_DIR=str(tmp_path / "cache"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gathered_on_every_rank"] is True
