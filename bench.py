@@ -633,6 +633,7 @@ def main():
     bounded = None
     main_info = ctx.pk_info(prover.pk_h)
     if args.bounded_gb > 0 and world == 1 and B and wit is None and not args.no_pipeline and \
+            args.workload == "arbo" and \
             args.table_budget_gb == 0 and args.window_g1 == 0 and args.window_g2 == 0:
         prover.close()
         prover = groth16.Prover(ctx, cc, pk, 0, 0, max_batch=max(B, 64),
@@ -660,15 +661,17 @@ def main():
         info = main_info
         traffic, traffic_source = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            import glob
+            pm_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))[-1]
+            pm = json.load(open(pm_path))
             if pm.get("batch") == B and pm.get("levels") == args.levels and \
                     args.workload == "arbo" and pm.get("g1_comb_k") == info["g1_comb_k"] and \
                     pm.get("populated") == args.populated:
                 traffic = pm["msm_g1_bytes_per_launch"]
-                traffic_source = ("profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / "
+                traffic_source = (f"profiles/{os.path.basename(pm_path)} (rocprofv3 --pmc FETCH_SIZE / "
                                   "WRITE_SIZE passes of tools/pmc_collect.sh over this build and "
                                   "plan; not collected inside this run)")
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         kname = ("msm_accumulate_comb<Fq, false>" if info["g1_comb_k"] else
                  "msm_accumulate_shared<Fq>" if info["g1_shared"] else "msm_accumulate<Fq, false>")
