@@ -161,21 +161,55 @@ def g2_from_bytes(buf: bytes) -> np.ndarray:
 
 
 # ---- Groth16 proof ---------------------------------------------------------------------------------
-def proof_to_bytes(proof32, raw=False) -> bytes:
-    """proof32: the 32-word record of zkmi_prove_batch (Ar | Krs | Bs).  gnark writes Ar, Bs, Krs."""
+def proof_to_bytes(proof32, raw=False, commitments=None, pok=None) -> bytes:
+    """proof32: the 32-word record of zkmi_prove_batch (Ar | Krs | Bs).  gnark writes Ar, Bs, Krs,
+    then the commitment extension: a uint32 count, the Commitments (the same point encoding as the
+    rest of the proof) and CommitmentPok [UPSTREAM-RECALL].  commitments: uint64 [n, 8], pok: [8]
+    (zkmi_prove_collect_ex's record split)."""
     a = np.asarray(proof32, dtype=np.uint64).reshape(32)
     ar, krs, bs = a[0:8], a[8:16], a[16:32]
     out = g1_to_bytes(ar, not raw) + g2_to_bytes(bs, not raw) + g1_to_bytes(krs, not raw)
-    return out + struct.pack(">I", 0)          # no commitments
+    if commitments is None or len(commitments) == 0:
+        return out + struct.pack(">I", 0)          # no commitments
+    cs = np.asarray(commitments, dtype=np.uint64).reshape(-1, 8)
+    out += struct.pack(">I", len(cs)) + b"".join(g1_to_bytes(c, not raw) for c in cs)
+    return out + g1_to_bytes(np.asarray(pok, dtype=np.uint64).reshape(8), not raw)
 
 
-def proof_from_bytes(buf: bytes) -> np.ndarray:
-    raw = len(buf) >= 64 + 128 + 64
+def proof_from_bytes(buf: bytes, with_commitments=False):
+    """-> proof record uint64 [32]; with_commitments: (record, commitments [n, 8], pok [8] | None)"""
+    raw = len(buf) >= 64 + 128 + 64 and (buf[0] & 0xC0) in (M_UNCOMPRESSED, M_INFINITY) and \
+        _looks_raw(buf)
     g1n, g2n = (64, 128) if raw else (32, 64)
     ar = g1_from_bytes(buf[:g1n])
     bs = g2_from_bytes(buf[g1n:g1n + g2n])
     krs = g1_from_bytes(buf[g1n + g2n:2 * g1n + g2n])
-    return np.concatenate([ar, krs, bs])
+    rec = np.concatenate([ar, krs, bs])
+    if not with_commitments:
+        return rec
+    o = 2 * g1n + g2n
+    n, = struct.unpack_from(">I", buf, o)
+    o += 4
+    coms = np.zeros((n, 8), dtype=np.uint64)
+    for i in range(n):
+        coms[i] = g1_from_bytes(buf[o:o + g1n])
+        o += g1n
+    pok = g1_from_bytes(buf[o:o + g1n]) if n else None
+    if len(buf) != o + (g1n if n else 0):
+        raise ValueError("malformed proof: trailing or missing bytes")
+    return rec, coms, pok
+
+
+def _looks_raw(buf):
+    """raw and compressed proofs are told apart by length: raw = 64 + 128 + 64 + 4 + (n + 1 if n) * 64"""
+    for g1n, g2n in ((64, 128), (32, 64)):
+        o = 2 * g1n + g2n
+        if len(buf) < o + 4:
+            continue
+        n, = struct.unpack_from(">I", buf, o)
+        if len(buf) == o + 4 + (n + 1 if n else 0) * g1n:
+            return g1n == 64
+    return len(buf) >= 64 + 128 + 64
 
 
 # ---- witness -----------------------------------------------------------------------------------------

@@ -101,3 +101,23 @@ def test_proving_and_verifying_key_round_trip(tmp_path):
         gnark_io.proving_key_from_bytes(bytes(bad), cc.n_public)
     with pytest.raises((ValueError, struct.error)):
         gnark_io.proving_key_from_bytes(blob[:1000], cc.n_public)
+
+
+def test_proof_with_commitments_roundtrip():
+    """Proof.WriteTo / WriteRawTo with the commitment extension: count, Commitments, CommitmentPok
+    behind the three proof points ([UPSTREAM-RECALL], parity unpinned)."""
+    g1 = _points(1, 5, 9)
+    g2 = _points(2, 1, 9)
+    rec = np.concatenate([g1[0], g1[1], g2[0]])
+    for raw in (False, True):
+        for n in (0, 1, 2):
+            b = gnark_io.proof_to_bytes(rec, raw, g1[2:2 + n], g1[4] if n else None)
+            size = (64 if raw else 32) * 2 + (128 if raw else 64) + 4 + ((n + 1) * (64 if raw else 32) if n else 0)
+            assert len(b) == size
+            back, coms, pok = gnark_io.proof_from_bytes(b, with_commitments=True)
+            assert np.array_equal(back, rec) and np.array_equal(coms, g1[2:2 + n])
+            assert (pok is None) == (n == 0) and (n == 0 or np.array_equal(pok, g1[4]))
+            assert np.array_equal(gnark_io.proof_from_bytes(b), rec)
+    with pytest.raises(ValueError):
+        gnark_io.proof_from_bytes(gnark_io.proof_to_bytes(rec, False, g1[2:3], g1[4]) + b"\\0",
+                                  with_commitments=True)
