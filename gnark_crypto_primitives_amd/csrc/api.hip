@@ -875,7 +875,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   }
   // validate every slot / constant / row index on the host before anything reaches a kernel
   enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT };
-  enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22 };
+  enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24 };
   std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
   const uint32_t* p = d->program;
   const size_t stride = (size_t)(1 + S) * 4;
@@ -902,7 +902,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
         for (uint32_t l = 0; l < S; l++) {
           const uint32_t* q = hh + 4 * (1 + l);
           if ((q[0] & 0x1f) == OP_END) continue;
-          if ((q[0] & 0x1f) != OP_PAIR || q[1] >= d->n_wires || q[2] >= d->n_wires || q[1] == q[2])
+          if ((q[0] & 0x1f) != OP_PAIR || q[1] >= d->n_slots || q[2] >= d->n_slots || q[1] == q[2])
             return bad(r + t);
           dsts.push_back(q[1]);
           srcs.push_back(q[2]);
@@ -987,8 +987,9 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
           break;
         case CLS_I:
           ok = op == OP_INV   ? (dst < d->n_slots && a < d->n_slots)
-               : op == OP_DIV ? (dst < d->n_slots && a < d->n_slots && b < d->n_slots)
-                              : false;
+               : (op == OP_DIV || op == OP_BXOR || op == OP_BAND)
+                   ? (dst < d->n_slots && a < d->n_slots && b < d->n_slots)
+                   : false;
           break;
         case CLS_BITS:
           // b = count | width << 16: count limbs of width bits (width 0 / 1: bits)

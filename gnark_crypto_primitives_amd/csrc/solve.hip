@@ -88,7 +88,7 @@ enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_
 // CLS_HIST / CLS_COMMIT do not fit the three class bits of an operand quad: their quads carry
 // class 0 and the class sits in the header quad.  OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22
 // (frontend/api.py).
-enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22 };
+enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24 };
 
 // Stores of the hot step classes.  gfx950 reads the data registers of a vector store out of order
 // with later VGPR writes, so the compiler waits for a store to complete (s_waitcnt vmcnt) before it
@@ -271,7 +271,21 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
         }
         break;
       case CLS_I:
-        if (op != OP_END) {
+        // the frontend never mixes the two kinds in one step (schedule.py: CLS_B), so the branch is
+        // wave-uniform up to idle sub-lanes
+        if (op == OP_BXOR || op == OP_BAND) {
+          // byte-op hints of the lookup tables: both operands as plain integers (low word), XOR / AND,
+          // back into the F domain (plain m times 2^522 through the F-domain product)
+          constexpr uint32_t c522[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
+                                        0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};
+          Fr k522;
+#pragma unroll
+          for (int t = 0; t < 8; t++) k522.v[t] = c522[t];
+          const Fr pa = f_plain(LD(x)), pb = f_plain(LD(y));
+          Fr pm = Fr::zero();
+          pm.v[0] = op == OP_BXOR ? (pa.v[0] ^ pb.v[0]) : (pa.v[0] & pb.v[0]);
+          STA(d, fmul(pm, k522));
+        } else if (op != OP_END) {
           const Fr va = LD(x), vy = LD(op == OP_DIV ? y : x);
           STA(d, op == OP_DIV ? fmul(va, finv(vy)) : finv(va));
         }

@@ -37,8 +37,11 @@ OP_END, OP_ADD, OP_SUB, OP_MUL, OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_BITS, OP_SE
 #     challenge into the value's slot, then the program continues
 # OP_BITS with b = count | width << 16: `count` limbs of `width` bits each (width 0 / 1: bits).
 OP_HIST, OP_HQ, OP_COMMIT = 20, 21, 22
+# bitwise XOR / AND of two small integers (< 2^32): the result hints of gnark's byte lookup tables
+# (std/internal/logderivprecomp: uints.Xor / And); unconstrained, the lookup constrains them
+OP_BXOR, OP_BAND = 23, 24
 
-HINT_INVZERO, HINT_NBITS, HINT_LIMBS, HINT_COUNT, HINT_COMMIT = 1, 2, 3, 4, 5
+HINT_INVZERO, HINT_NBITS, HINT_LIMBS, HINT_COUNT, HINT_COMMIT, HINT_BYTEOP = 1, 2, 3, 4, 5, 6
 FIELD_BITS = 254      # bit length of r
 
 
@@ -212,6 +215,30 @@ class API:
             res = Variable(_lc_add(res.lc, x.lc), val)
         return res
 
+    def Sum(self, xs):
+        """Add over a long list: the linear expression is merged in place (a chain of Add would
+        copy the growing expression every time) and the values are added pairwise (a tree, so the
+        witness program's dependency chain is logarithmic)."""
+        xs = [self._v(x) for x in xs]
+        xs = [x for x in xs if x.lc]
+        if not xs:
+            return self._const(0)
+        lc = {}
+        for x in xs:
+            for w, c in x.lc.items():
+                v = (lc.get(w, 0) + c) % R
+                if v:
+                    lc[w] = v
+                else:
+                    lc.pop(w, None)
+        vals = [x.val for x in xs]
+        while len(vals) > 1:
+            nxt = [self._emit(OP_ADD, vals[i], vals[i + 1]) for i in range(0, len(vals) - 1, 2)]
+            if len(vals) % 2:
+                nxt.append(vals[-1])
+            vals = nxt
+        return Variable(lc, vals[0])
+
     def Neg(self, a):
         a = self._v(a)
         if not a.lc:
@@ -290,6 +317,43 @@ class API:
         res, w = self._internal(val)
         self._add_r1c(res, b, a, solve_wire=w, check=True)
         return res
+
+    def _batch_inverse_vals(self, xs):
+        """SSA values of 1 / x_i (0 for x_i = 0) from ONE field inversion: an OP_BATCHINV unit
+        (Montgomery's trick in the solver kernel).  Values only: no wires, no constraints."""
+        vals = [self._new_val() for _ in xs]
+        self.ops.append((OP_BATCHINV, len(xs), 0, 0))
+        for v, x in zip(vals, xs):
+            self.ops.append((OP_PAIR, v, x.val, 0))
+        return vals
+
+    def InverseBatch(self, xs):
+        """[Inverse(x) for x in xs] -- the same wires and constraints (res_i * x_i == 1) -- with the
+        witness computed by one shared inversion instead of one per element (the lookup arguments
+        invert tens of thousands of independent values)."""
+        xs = [self._v(x) for x in xs]
+        if any(x.is_const() for x in xs) or len(xs) < 4:
+            return [self.Inverse(x) for x in xs]
+        out = []
+        one = self._const(1)
+        for val, x in zip(self._batch_inverse_vals(xs), xs):
+            res, w = self._internal(val)
+            self._add_r1c(res, x, one, solve_wire=w, check=True)
+            out.append(res)
+        return out
+
+    def DivUncheckedBatch(self, nums, dens):
+        """[DivUnchecked(a, b) for a, b in zip(nums, dens)] with one shared inversion (0 / 0 = 0)."""
+        nums, dens = [self._v(a) for a in nums], [self._v(b) for b in dens]
+        if any(b.is_const() for b in dens) or any(not a.lc for a in nums) or len(dens) < 4:
+            return [self.DivUnchecked(a, b) for a, b in zip(nums, dens)]
+        out = []
+        for inv, a, b in zip(self._batch_inverse_vals(dens), nums, dens):
+            val = self._emit(OP_MUL, a.val, inv)
+            res, w = self._internal(val)
+            self._add_r1c(res, b, a, solve_wire=w, check=True)
+            out.append(res)
+        return out
 
     def Div(self, a, b):
         """gnark Div: asserts b != 0 by computing its inverse, then multiplies."""
@@ -516,6 +580,21 @@ class API:
         self.hints.append((HINT_LIMBS, [{0: width}, a.lc], wires))
         self.instr.append((1, len(self.hints) - 1))
         return [Variable({w: 1}, v) for w, v in zip(wires, vals)]
+
+    def NewHintByteOp(self, op, x, y):
+        """Unconstrained hint (uints xorHint / andHint): x XOR y or x AND y of two small integers,
+        as a fresh internal wire.  op: OP_BXOR | OP_BAND."""
+        if op not in (OP_BXOR, OP_BAND):
+            raise CompileError("byte-op hint: OP_BXOR or OP_BAND")
+        x, y = self._v(x), self._v(y)
+        if x.is_const() and y.is_const():
+            a, b = x.const_value(), y.const_value()
+            return self._const(a ^ b if op == OP_BXOR else a & b)
+        val = self._emit(op, x.val, y.val)
+        res, w = self._internal(val)
+        self.hints.append((HINT_BYTEOP, [{0: 1 if op == OP_BXOR else 2}, x.lc, y.lc], [w]))
+        self.instr.append((1, len(self.hints) - 1))
+        return res
 
     def NewHintCount(self, queries, table_size):
         """Unconstrained hint (std/lookup/logderivarg countHint for the table 0 .. size - 1):

@@ -13,8 +13,8 @@ import hashlib
 
 import numpy as np
 
-from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS,
-                  OP_COMMIT, OP_COPY, OP_DIV, OP_END, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC,
+from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BAND, OP_BATCHINV,
+                  OP_BITS, OP_BXOR, OP_COMMIT, OP_COPY, OP_DIV, OP_END, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC,
                   OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_XOR, OP_XORABC,
                   OP_SUB, R)
 
@@ -123,6 +123,8 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         if op == OP_ABC:
             return (op | chk.get(i, 0) << 5 | c << 6 | row_of[i] << 9, slot[dst], slot[a], slot[b])
         w0 = op | c << 6 | (row_of[i] << 9 if i in row_of else 0)
+        if op in (OP_BXOR, OP_BAND):       # scheduled as CLS_B, executed by the kernel's CLS_I arm
+            return (op | sch.CLS_I << 6, slot[dst], slot[a], slot[b])
         if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR):
             return (w0, slot[dst], slot[a], slot[b])
         if op in (OP_MULC, OP_ADDC):
@@ -140,7 +142,19 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         # destinations first get their slots (sources are all older values)
         for i in idxs:
             op, dst, a, b = ops[i][:4]
-            if op in (OP_ABC, OP_BATCHINV, OP_BITS, OP_HIST, OP_COMMIT):
+            if op == OP_BATCHINV:           # results of the unit: wires, or temporaries (api.py)
+                for q in range(1, dst + 1):
+                    d2 = ops[i + q][1]
+                    if d2 not in slot:
+                        if free:
+                            slot[d2] = free.pop()
+                        else:
+                            slot[d2] = n_slots
+                            n_slots += 1
+                        if d2 not in last:
+                            released.append(slot[d2])
+                continue
+            if op in (OP_ABC, OP_BITS, OP_HIST, OP_COMMIT):
                 continue
             if dst not in slot:
                 if free:
@@ -183,8 +197,9 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
                 rows.append([(c, n_q, 0, aux), (OP_COMMIT, slot[dst], 0, aux)] +
                             [(0, 0, 0, 0)] * (S - 1))
         else:
+            kc = sch.CLS_I if c == sch.CLS_B else c       # class the kernel sees
             quads = [quad(i, c) for i in idxs]
-            rows.append([hdr] + quads + [(c << 6, 0, 0, 0)] * (S - len(quads)))
+            rows.append([(kc, len(idxs), 0, 0)] + quads + [(kc << 6, 0, 0, 0)] * (S - len(quads)))
         # temporaries whose last reader is this step return to the pool for LATER steps
         for i in idxs:
             op, dst, a, b = ops[i][:4]
@@ -289,14 +304,14 @@ class CompiledCircuit:
             elif op == OP_BITS:
                 keep[i] = True
                 live[a] = True
-            elif op in (OP_HIST, OP_COMMIT):
+            elif op in (OP_HIST, OP_COMMIT, OP_BATCHINV):
                 keep[i] = True
-            elif op == OP_HQ:
+            elif op in (OP_HQ, OP_PAIR):
                 keep[i] = True
                 live[a] = True
             elif live[dst]:
                 keep[i] = True
-                if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+                if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_BXOR, OP_BAND):
                     live[a] = live[b] = True
                 elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY):
                     live[a] = True
@@ -316,7 +331,7 @@ class CompiledCircuit:
         for i, (op, dst, a, b) in enumerate(ops):
             if op == OP_ABC:
                 last[dst] = last[a] = last[b] = i
-            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC):
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_BXOR, OP_BAND):
                 last[a] = last[b] = i
             elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS, OP_PAIR, OP_HQ):
                 last[a] = i
@@ -332,7 +347,13 @@ class CompiledCircuit:
                 prog[i] = (op, dst, 0, 0)           # dst field = number of (dst, src) rows
                 continue
             if op == OP_PAIR:
-                prog[i] = (op, slot[dst], slot[a], 0)   # both wire-backed, never recycled
+                if dst not in slot:                     # a temporary result (api._batch_inverse_vals)
+                    if free:
+                        slot[dst] = free.pop()
+                    else:
+                        slot[dst] = n_slots
+                        n_slots += 1
+                prog[i] = (op, slot[dst], slot[a], 0)
                 continue
             if op in (OP_HIST, OP_COMMIT):
                 prog[i] = (op, slot[dst], a, b)         # dst wire-backed; a operand rows follow
@@ -348,15 +369,17 @@ class CompiledCircuit:
                 flag = 0x100 if api.constraints[n_abc][5] else 0
                 n_abc += 1
                 prog[i] = (op | flag, slot[dst], slot[a], slot[b])
-            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC):
+            elif op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_BXOR, OP_BAND):
                 srcs = (a, b)
                 if op in (OP_MULABC, OP_XORABC):
                     n_abc += 1
             elif op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
                 srcs = (a,)
             sa = slot[a] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULC, OP_ADDC, OP_NEG,
-                                   OP_INV, OP_COPY, OP_BITS, OP_MULABC, OP_XORABC) else 0
-            sb = slot[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC) else b
+                                   OP_INV, OP_COPY, OP_BITS, OP_MULABC, OP_XORABC, OP_BXOR,
+                                   OP_BAND) else 0
+            sb = slot[b] if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_BXOR,
+                                   OP_BAND) else b
             for s in set(srcs):
                 if last.get(s) == i and s not in val_wire:
                     free.append(slot[s])
@@ -477,6 +500,9 @@ class CompiledCircuit:
                     writes.append((d, pow(s[x], R - 2, R)))
                 elif op == OP_DIV:
                     writes.append((d, s[x] * pow(s[y], R - 2, R) % R))
+                elif op in (OP_BXOR, OP_BAND):       # low 32 bits, as the kernel
+                    u, v = s[x] & 0xffffffff, s[y] & 0xffffffff
+                    writes.append((d, u ^ v if op == OP_BXOR else u & v))
                 elif op == OP_ABC:
                     a_[k], b_[k], c_[k] = s[d], s[x], s[y]
                     if chk and s[d] * s[x] % R != s[y]:
@@ -544,6 +570,9 @@ class CompiledCircuit:
                 s[d] = pow(s[a], R - 2, R)
             elif op == OP_DIV:
                 s[d] = s[a] * pow(s[b], R - 2, R) % R
+            elif op in (OP_BXOR, OP_BAND):
+                u, v = s[a] & 0xffffffff, s[b] & 0xffffffff
+                s[d] = u ^ v if op == OP_BXOR else u & v
             elif op == OP_BITS:
                 v, width = s[a], (b >> 16) or 1
                 for k in range(b & 0xffff):

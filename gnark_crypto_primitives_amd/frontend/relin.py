@@ -164,12 +164,17 @@ def relinearize(ops, val_wire, consts, n_vals):
                 del lin[dst]
             continue
         if op == OP_BATCHINV:
-            out.append((op, dst, a, b))
+            pairs = []
             for _ in range(dst):
                 o = ops[i]
                 i += 1
-                out.append(o)                        # (OP_PAIR, dst wire, src wire): inputs only
-                depth[o[1]] = 4000
+                pairs.append((o[0], o[1], use(o[2]), 0))   # sources may be linear values: materialise
+            # materialisations emitted by use() come first, then the unit and its rows back to back
+            out.append((op, dst, a, b))
+            out.extend(pairs)
+            d0 = max([dep(o[2]) for o in pairs], default=0) + 4000
+            for o in pairs:
+                depth[o[1]] = d0
             continue
         if op in (OP_HIST, OP_COMMIT):
             # operand rows: materialised values; the unit defines wire-backed values only

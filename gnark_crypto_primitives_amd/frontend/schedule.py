@@ -23,22 +23,25 @@ from __future__ import annotations
 
 import heapq
 
-from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COMMIT, OP_COPY, OP_DIV, OP_HIST,
-                  OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR,
-                  OP_XORABC)
+from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BAND, OP_BATCHINV, OP_BITS, OP_BXOR, OP_COMMIT, OP_COPY,
+                  OP_DIV, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC,
+                  OP_SUB, OP_XOR, OP_XORABC)
 
 OP_FMAC, OP_FMA = 18, 19       # relin.py: (op, dst, x, const, addend) / (op, dst, x, y, addend)
-CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT = range(1, 10)
+CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B = range(1, 11)
+# CLS_B (byte-op hints) is a scheduling class of its own -- a step never mixes them with inversions --
+# but runs in the kernel's CLS_I arm (its quads carry class CLS_I)
 # the class field of an operand quad has three bits: HIST / COMMIT rows carry 0 there and their
 # class in the header quad
 SINGLE = (CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT)
 CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_FMA: CLS_M, OP_XORABC: CLS_X, OP_XOR: CLS_X,
             OP_ADD: CLS_A, OP_SUB: CLS_A, OP_ADDC: CLS_A, OP_NEG: CLS_A, OP_COPY: CLS_A,
             OP_SETC: CLS_A, OP_ABC: CLS_R, OP_INV: CLS_I, OP_DIV: CLS_I, OP_BITS: CLS_BITS,
-            OP_BATCHINV: CLS_BINV, OP_HIST: CLS_HIST, OP_COMMIT: CLS_COMMIT}
+            OP_BATCHINV: CLS_BINV, OP_HIST: CLS_HIST, OP_COMMIT: CLS_COMMIT, OP_BXOR: CLS_B,
+            OP_BAND: CLS_B}
 # relative time of one step of the class on a lone wavefront (instruction counts / 40)
 COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000,
-        CLS_HIST: 4000, CLS_COMMIT: 20000}
+        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20}
 
 
 def n_rows_of(o):
@@ -59,7 +62,7 @@ def reads_of(op, dst, a, b, z=None):
         return (a, z)
     if op == OP_ABC:
         return (dst, a, b)
-    if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR):
+    if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MULABC, OP_XORABC, OP_XOR, OP_BXOR, OP_BAND):
         return (a, b)
     if op in (OP_MULC, OP_ADDC, OP_NEG, OP_INV, OP_COPY, OP_BITS):
         return (a,)

@@ -7,25 +7,33 @@ challenge from a commitment to the table's variable entries, the queries and the
 (std/multicommit).  Rows of several columns are folded with powers of the challenge.  Cost: one
 constraint per table row (a division), one per query (an inversion), plus the commitment.
 
-This build supports the table shape the range checker needs -- one column holding the constants
-0 .. n - 1 -- whose multiplicities the solver counts with one histogram instruction (OP_HIST)."""
+This build supports one-column tables of constants -- the range checker's 0 .. n - 1 and the packed
+tables of std/logderivprecomp.py (x | y << 8 | f(x, y) << 16) -- whose multiplicities the solver
+counts with one histogram instruction (OP_HIST) over the queries' row indices."""
 from . import multicommit
 
 
 def BuildRange(api, table_size, queries):
     """table = [0, 1, ..., table_size - 1] (constants), one-column queries."""
     queries = list(queries)
+    Build(api, range(table_size), queries, queries)
+
+
+def Build(api, table_values, queries, row_index):
+    """table_values: the constant table entries t_0 .. t_(n-1); queries: the looked-up values;
+    row_index[i]: a variable holding the table row query i claims (only the multiplicity HINT uses
+    it: a wrong index makes the argument fail, it cannot make a wrong query pass)."""
+    queries, row_index = list(queries), list(row_index)
+    table_values = [int(t) for t in table_values]
     if not queries:
         return
-    mults = api.NewHintCount(queries, table_size)
+    mults = api.NewHintCount(row_index, len(table_values))
 
     def cb(api, challenge):
-        lp = 0
-        for j, m in enumerate(mults):
-            lp = api.Add(lp, api.DivUnchecked(m, api.Sub(challenge, j)))
-        rp = 0
-        for q in queries:
-            rp = api.Add(rp, api.Inverse(api.Sub(challenge, q)))
+        # same constraints as gnark's DivUnchecked / Inverse per row; the witness side shares one
+        # inversion per argument (api.DivUncheckedBatch / InverseBatch)
+        lp = api.Sum(api.DivUncheckedBatch(mults, [api.Sub(challenge, t) for t in table_values]))
+        rp = api.Sum(api.InverseBatch([api.Sub(challenge, q) for q in queries]))
         api.AssertIsEqual(lp, rp)
 
     multicommit.WithCommitment(api, cb, *queries, *mults)

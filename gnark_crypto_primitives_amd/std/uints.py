@@ -11,6 +11,9 @@ returns its eight bytes little-endian; every U8 is constrained to [0, 256).
 """
 
 
+_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
 class U8:
     """uints.U8: ``Val`` is the byte as a field variable; ``bits`` (LSB first) are its boolean
     wires when they are already known, so that bitwise gadgets do not decompose twice."""
@@ -77,3 +80,55 @@ class BinaryField:
 
     def AssertEq(self, a, b):
         self.api.AssertIsEqual(a.Val, b.Val)
+
+    # ---- byte-wise logic the way gnark's uints does it (commit mode): lookup tables + range checks --
+    def _table(self, op):
+        from . import logderivprecomp
+        if self.rchecker is None:
+            raise ValueError("byte-wise Xor / And / Not / Lrot need BinaryField(api, commit=True)")
+        return logderivprecomp.New(self.api, op)
+
+    def _two(self, op, a, b):
+        return [U8(self._table(op).Query(x.Val, y.Val)) for x, y in zip(a, b)]
+
+    def Xor(self, a, *rest):
+        """uints.BinaryField.Xor: bytes through the 2^16-row XOR table, operand by operand."""
+        from ..frontend.api import OP_BXOR
+        for b in rest:
+            a = self._two(OP_BXOR, a, b)
+        return list(a)
+
+    def And(self, a, *rest):
+        from ..frontend.api import OP_BAND
+        for b in rest:
+            a = self._two(OP_BAND, a, b)
+        return list(a)
+
+    def Not(self, a):
+        """uints.BinaryField.Not: XOR with 0xff through the table (as gnark does)."""
+        from ..frontend.api import OP_BXOR
+        return self._two(OP_BXOR, a, [U8(0xff)] * len(a))
+
+    def Lrot(self, a, c):
+        """uints.BinaryField.Lrot: rotate the word left by c bits.  Whole bytes move by renaming; the
+        remaining c % 8 bits split every byte with bitslice.Partition (a hint for the low part, the
+        high part follows linearly; both range-checked) and stitch neighbours together."""
+        n = len(a)
+        c %= 8 * n
+        shift_bl, shift_bt = c // 8, c % 8
+        if shift_bt == 0:
+            return [a[(i - shift_bl) % n] for i in range(n)]
+        rev = 8 - shift_bt
+        parts = []
+        for b in a:
+            lo = self.api.NewHintLimbs(b.Val, rev, 1)[0]                  # low `rev` bits of the byte
+            hi = self.api.Mul(self.api.Sub(b.Val, lo), pow(1 << rev, -1, _R))   # (b - lo) / 2^rev
+            self.rchecker.Check(lo, rev)
+            self.rchecker.Check(hi, shift_bt)
+            parts.append((lo, hi))
+        out = [None] * n
+        for i in range(n):
+            # new byte = low part shifted up + high part of the byte below
+            out[(i + shift_bl) % n] = U8(self.api.Add(self.api.Mul(parts[i][0], 1 << shift_bt),
+                                                      parts[(i - 1) % n][1]))
+        return out
