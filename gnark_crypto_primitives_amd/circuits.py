@@ -115,11 +115,13 @@ class AddressCircuit:
     Y = Secret(4)
 
     commit = False
+    byte_tables = False
 
     def define(self, api):
         from .ecc.secp256k1 import DeriveAddress, PublicKey
         from .std.emulated import Element
-        addr = DeriveAddress(api, PublicKey(Element(self.X), Element(self.Y)), self.commit)
+        addr = DeriveAddress(api, PublicKey(Element(self.X), Element(self.Y)), self.commit,
+                             self.byte_tables)
         api.AssertIsEqual(self.Address, addr)
 
 
@@ -128,3 +130,11 @@ class AddressCircuitCommit(AddressCircuit):
     an R1CS builder: log-derivative lookup + Groth16 commitment (std/rangecheck.py).  A proof of it
     carries one Pedersen commitment and its proof of knowledge."""
     commit = True
+
+
+class AddressCircuitByteTables(AddressCircuit):
+    """The address circuit the way gnark compiles ``ecdsa.DeriveAddress``: bytes all the way --
+    Keccak-f over uints.U64 lanes with the 2^16-row XOR / AND lookup tables, rotations through range
+    checks, one Groth16 commitment behind all of them (std/sha3.py::permute_bytes, std/uints.py,
+    std/logderivprecomp.py)."""
+    byte_tables = True

@@ -13,13 +13,16 @@ class PublicKey:
         self.X, self.Y = X, Y
 
 
-def DeriveAddress(api, pub_key, commit=False):
+def DeriveAddress(api, pub_key, commit=False, byte_tables=False):
     """commit: byte range checks through gnark's commitment-based checker (what ``uints.New`` gives
-    an R1CS builder) instead of boolean wires."""
+    an R1CS builder) instead of boolean wires.  byte_tables: the whole gadget the way gnark compiles
+    it -- Keccak over uints.U64 with the XOR / AND lookup tables (std/sha3.py::permute_bytes) instead
+    of this repo's boolean Keccak (implies commit)."""
+    commit = commit or byte_tables
     x_bytes = utils.ElemToU8(api, pub_key.X, commit)
     y_bytes = utils.ElemToU8(api, pub_key.Y, commit)
     pub_bytes = utils.SwapEndianness(x_bytes) + utils.SwapEndianness(y_bytes)
-    keccak = sha3.NewLegacyKeccak256(api)
+    keccak = sha3.NewLegacyKeccak256Bytes(api) if byte_tables else sha3.NewLegacyKeccak256(api)
     keccak.Write(pub_bytes)
     digest = keccak.Sum()
     return utils.U8ToVar(api, digest[12:])

@@ -110,3 +110,62 @@ class LegacyKeccak256:
 
 def NewLegacyKeccak256(api):
     return LegacyKeccak256(api)
+
+
+# ---- the byte-wise form: gnark's std/permutation/keccakf over uints.U64 [UPSTREAM-RECALL] ---------------
+def permute_bytes(bf, A):
+    """Keccak-f[1600] on A[x][y] = uints.U64 (eight range-checked bytes, least significant first),
+    with gnark's uints operations: Xor / And / Not are lookups into 2^16-row tables, rotations by
+    whole bytes are renamings, the other rotations split bytes with range checks (uints.Lrot).
+    Per round: 76 Xor64 + 25 And64 + 25 Not64 = 1 008 byte lookups, 27 bit-level rotations."""
+    for rnd in range(24):
+        C = [bf.Xor(A[x][0], A[x][1], A[x][2], A[x][3], A[x][4]) for x in range(5)]
+        D = [bf.Xor(C[(x - 1) % 5], bf.Lrot(C[(x + 1) % 5], 1)) for x in range(5)]
+        A = [[bf.Xor(A[x][y], D[x]) for y in range(5)] for x in range(5)]
+        B = [[None] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                B[y][(2 * x + 3 * y) % 5] = bf.Lrot(A[x][y], ROT[x][y])
+        A = [[bf.Xor(B[x][y], bf.And(bf.Not(B[(x + 1) % 5][y]), B[(x + 2) % 5][y]))
+              for y in range(5)] for x in range(5)]
+        rc = [U8((RC[rnd] >> (8 * i)) & 0xff) for i in range(8)]
+        A[0][0] = bf.Xor(A[0][0], rc)
+    return A
+
+
+class LegacyKeccak256Bytes:
+    """sha3.NewLegacyKeccak256 as gnark builds it for an R1CS: the sponge over uints.U64 lanes."""
+    def __init__(self, api):
+        self.api = api
+        self.bf = BinaryField(api, commit=True)
+        self.data = []
+
+    def Write(self, data):
+        self.data.extend(data)
+
+    def Size(self):
+        return 32
+
+    def Sum(self):
+        bf = self.bf
+        msg = list(self.data)
+        pad = RATE_256 - len(msg) % RATE_256
+        tail = [0] * pad
+        tail[0] |= 0x01
+        tail[-1] |= 0x80
+        msg += [U8(t) for t in tail]
+        A = [[[U8(0)] * 8 for _ in range(5)] for _ in range(5)]
+        for off in range(0, len(msg), RATE_256):
+            block = msg[off:off + RATE_256]
+            for k in range(RATE_256 // 8):
+                x, y = k % 5, k // 5
+                A[x][y] = bf.Xor(A[x][y], block[8 * k:8 * k + 8])
+            A = permute_bytes(bf, A)
+        out = []
+        for k in range(4):
+            out += A[k % 5][k // 5]
+        return out
+
+
+def NewLegacyKeccak256Bytes(api):
+    return LegacyKeccak256Bytes(api)

@@ -10,7 +10,7 @@ from .tree import smt_witness
 
 R = poseidon_native.R
 NAMES = ("arbo", "poseidon", "verifier", "elgamal-add", "elgamal-encrypt", "address",
-         "address-commit")
+         "address-commit", "address-bytes")
 
 
 def _poseidon(rng):
@@ -79,4 +79,8 @@ def build(name, levels=160, populated=10):
         return (circuits.AddressCircuitCommit(), _address,
                 "secp256k1 address derivation, Keccak-256 in R1CS, bytes range-checked through "
                 "gnark's commitment-based checker (config 5 with the Groth16 commitment extension)")
+    if name == "address-bytes":
+        return (circuits.AddressCircuitByteTables(), _address,
+                "secp256k1 address derivation the way gnark compiles it: byte-wise Keccak-256 over "
+                "uints.U64 with XOR / AND lookup tables, one Groth16 commitment (config 5)")
     raise ValueError(f"unknown workload {name!r}; one of {NAMES}")

@@ -63,6 +63,8 @@ def compiled(name):
         return compile_circuit(circuits.AddressCircuit())
     if name == "address-commit":
         return compile_circuit(circuits.AddressCircuitCommit())
+    if name == "address-bytes":
+        return compile_circuit(circuits.AddressCircuitByteTables())
     if name == "address-scs":
         from gnark_crypto_primitives_amd.frontend.scs import compile_scs
         return compile_scs(compiled("address"))

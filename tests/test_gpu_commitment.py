@@ -124,3 +124,22 @@ def test_byte_lookup_tables_on_gpu(zk_ctx):
         asg.append({"X": x, "Y": y, "Z": ByteOpsCircuit.expected(x, y)})
     asg[4]["Z"] ^= 1 << 17
     _check(zk_ctx, cc, asg, [4], 61, wbits=(8, 6), publics=[[a["Z"]] for a in asg], max_batch=64)
+
+
+def test_config5_address_as_gnark_compiles_it(zk_ctx):
+    """ecdsa.DeriveAddress with everything on bytes, as gnark's uints / sha3 build it: 217 366
+    constraints, 378 133 wires, 174 272 of them behind one commitment, domain 2^18.  Three proofs
+    (public vectors for keys 1 and 2), one with a wrong address; proof, commitment and proof of
+    knowledge bit-exact against the C oracle, verifying under the product's verifier."""
+    from gnark_crypto_primitives_amd.std.emulated import limbs_of
+    from oracle import pyref
+    cc = H.compiled("address-bytes")
+    assert cc.domain_log2() == 18 and len(cc.commitments) == 1
+    asg = []
+    for priv in (1, 2, 0xC0FFEE):
+        pub = pyref.secp256k1_mul(priv)
+        asg.append({"Address": pyref.eth_address(pub), "X": limbs_of(pub[0]), "Y": limbs_of(pub[1])})
+    assert asg[0]["Address"] == 0x7E5F4552091A69125D5DFCB7B8C2659029395BDF
+    asg[2] = dict(asg[2], Address=asg[1]["Address"])
+    _check(zk_ctx, cc, asg, [2], 58, wbits=(0, 0), publics=[[a["Address"]] for a in asg],
+           max_batch=64)
