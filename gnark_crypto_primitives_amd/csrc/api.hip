@@ -749,6 +749,12 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
   pk->n_z = n_z;
   pk->max_batch = d->max_batch ? d->max_batch : 1024;
   int rc;
+  // commitment keys first (per-window tables of the Pedersen bases, 2 x 33 KB per committed wire at
+  // the widest setting): the plan below is sized against the HBM that is free AFTER them
+  if ((rc = commit_keys_load(ctx, d, pk))) {
+    zkmi_pk_free(ctx, pk);
+    return rc;
+  }
   // One window plan per group for the whole key.  Auto plans are sized against the free HBM minus
   // the working set of the largest batch the caller will prove (and the caller's own cap).
   const bool auto1 = d->window_bits_g1 == 0, auto2 = d->window_bits_g2 == 0;
@@ -828,10 +834,6 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       zkmi_pk_free(ctx, pk);
       return rc;
     }
-  }
-  if ((rc = commit_keys_load(ctx, d, pk))) {
-    zkmi_pk_free(ctx, pk);
-    return rc;
   }
   hipMemcpy(&pk->alpha, d->g1_alpha, 64, hipMemcpyDefault);
   hipMemcpy(&pk->beta1, d->g1_beta, 64, hipMemcpyDefault);
