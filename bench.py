@@ -371,6 +371,9 @@ def main():
                          "rounds with the Fiat-Shamir hashing on the host between them)")
     ap.add_argument("--msm-chunk-factor", type=int, default=0,
                     help="zkmi_pk_desc.msm_chunk_factor (0 = the library's default, 16 for comb tables)")
+    ap.add_argument("--sparse-witness", type=int, default=-1,
+                    help="zkmi_pk_desc.sparse_witness (0 dense / 1 mostly small values / 2 all bits); "
+                         "-1 = from the circuit's share of boolean wires")
     ap.add_argument("--solver-lanes", type=int, default=0,
                     help="sub-lanes of the witness solver per proof (zkmi_cs_desc.lanes_per_proof); "
                          "0 = the frontend's choice (shortest schedule)")
@@ -486,7 +489,8 @@ def main():
     t1 = time.time()
     prover = groth16.Prover(ctx, cc, pk, args.window_g1, args.window_g2, max_batch=max(B, 64),
                             msm_chunk_factor=args.msm_chunk_factor,
-                            table_budget_bytes=int(args.table_budget_gb * 1e9))
+                            table_budget_bytes=int(args.table_budget_gb * 1e9),
+                            sparse_witness=None if args.sparse_witness < 0 else args.sparse_witness)
     startup["key_load_s"] = time.time() - t1
     log(f"key resident, window tables built ({time.time() - t0:.1f}s)")
 
