@@ -366,6 +366,12 @@ def prove_fast(key, a, b, c, public, blind):
     def commit_m(cf):
         return g1_from_image(cref.msm(1, srs[:len(cf)], cf))
 
+    def commit_many(cfs):
+        """independent commitments side by side (ctypes releases the GIL around the C MSM)"""
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(cfs)) as ex:
+            return list(ex.map(commit_m, cfs))
+
     def ev_at(cf, x):
         out = np.zeros(4, np.uint64)
         xm = _m1(x)
@@ -373,7 +379,7 @@ def prove_fast(key, a, b, c, public, blind):
         return _unmont(out)[0]
     am, bm, cm = (mont(list(v)) for v in (a, b, c))
     ca, cb, cc = blinded(am, blind[0:2]), blinded(bm, blind[2:4]), blinded(cm, blind[4:6])
-    A, B, Cc = commit_m(ca), commit_m(cb), commit_m(cc)
+    A, B, Cc = commit_many([ca, cb, cc])
     vkd = vk_digest(key)
     gamma = challenge("gamma", vkd, *public, A, B, Cc)
     beta = challenge("beta", gamma)
@@ -396,7 +402,7 @@ def prove_fast(key, a, b, c, public, blind):
     assert not ct[3 * n + 6:].any(), "quotient degree too high: the witness does not satisfy the system"
     tlo, tmid, thi = (np.ascontiguousarray(x) for x in
                       (ct[:n + 2], ct[n + 2:2 * n + 4], ct[2 * n + 4:3 * n + 6]))
-    TLO, TMID, THI = commit_m(tlo), commit_m(tmid), commit_m(thi)
+    TLO, TMID, THI = commit_many([tlo, tmid, thi])
     zeta = challenge("zeta", alpha, TLO, TMID, THI)
     ev = (ev_at(ca, zeta), ev_at(cb, zeta), ev_at(cc, zeta), ev_at(coef_m["s1"], zeta),
           ev_at(coef_m["s2"], zeta), ev_at(cz, zeta * w % R))
@@ -429,8 +435,9 @@ def prove_fast(key, a, b, c, public, blind):
     nz[0] = _m1(_unmont(nz[0:1])[0] - ev[5])
     wzw = np.zeros((len(nz) - 1, 4), np.uint64)
     lib.zkref_div_linear(P(nz), C.c_size_t(len(nz)), P(_m1(zeta * w % R)), P(wzw))
+    WZ, WZW = commit_many([wz, wzw])
     return {"a": A, "b": B, "c": Cc, "z": Z, "tlo": TLO, "tmid": TMID, "thi": THI,
-            "wz": commit_m(wz), "wzw": commit_m(wzw), "ev": ev}
+            "wz": WZ, "wzw": WZW, "ev": ev}
 
 
 def lin_scalars(key, public, beta, gamma, alpha, zeta, ev):

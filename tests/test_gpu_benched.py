@@ -57,7 +57,7 @@ def test_arbo160_auto_plan_pipelined_vs_oracle(zk_ctx):
     rh, ph = cref.R1csHandle(cc), cref.PkHandle(pk)
     rng = random.Random(2024)
     try:
-        for populated, distinct in ((10, 384), (159, 160)):
+        for populated, distinct in ((10, 384), (159, 96)):
             batches = _batches(cc, rng, populated, 3, distinct)
             got = list(prover.prove_stream([(i, r) for i, r, _ in batches]))
             for k, ((inp, rs, bad), (proofs, status)) in enumerate(zip(batches, got)):

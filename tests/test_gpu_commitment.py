@@ -13,7 +13,7 @@ from gnark_crypto_primitives_amd import circuits, groth16, lib, verify
 from gnark_crypto_primitives_amd.frontend import compile_circuit
 from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
 from tests import helpers as H
-from tests.test_commitment import ByteOpsCircuit, RangeCircuit, TwoCommitments
+from tests.test_commitment import RangeCircuit, TwoCommitments
 
 pytestmark = pytest.mark.gpu
 
@@ -110,20 +110,6 @@ def test_config5_address_with_commitment_range_checks(zk_ctx):
     asg[4] = dict(asg[4], X=x)
     _check(zk_ctx, cc, asg, [3, 4], 57, wbits=(0, 0), publics=[[a["Address"]] for a in asg],
            max_batch=64)
-
-
-def test_byte_lookup_tables_on_gpu(zk_ctx):
-    """gnark-style uints on bytes (std/logderivprecomp tables, 131 k constraints, 131 k committed
-    wires, domain 2^18): solver ops OP_BXOR / OP_BAND, OP_HIST over 65 536-row tables, batched
-    inversions; proofs, commitment and proof of knowledge bit-exact against the C oracle."""
-    cc = compile_circuit(ByteOpsCircuit(), 16)
-    rng = random.Random(77)
-    asg = []
-    for _ in range(6):
-        x, y = rng.getrandbits(64), rng.getrandbits(64)
-        asg.append({"X": x, "Y": y, "Z": ByteOpsCircuit.expected(x, y)})
-    asg[4]["Z"] ^= 1 << 17
-    _check(zk_ctx, cc, asg, [4], 61, wbits=(8, 6), publics=[[a["Z"]] for a in asg], max_batch=64)
 
 
 def test_config5_address_as_gnark_compiles_it(zk_ctx):

@@ -204,11 +204,13 @@ def test_config4_elgamal_add(zk_ctx):
     def enc(m):
         k = rng.randrange(bjj.ORDER)
         return bjj.mul(bjj.BASE, k) + bjj.add(bjj.mul(bjj.BASE, m), bjj.mul(pub, k))
-    asg = []
-    for i in range(70):
+    distinct = []
+    for i in range(18):                       # 0.1 s each: Python curve arithmetic
         a, b = enc(i), enc(1000 - i)
-        asg.append({"A": list(a), "B": list(b),
-                    "Sum": list(bjj.add(a[:2], b[:2]) + bjj.add(a[2:], b[2:]))})
+        distinct.append({"A": list(a), "B": list(b),
+                         "Sum": list(bjj.add(a[:2], b[:2]) + bjj.add(a[2:], b[2:]))})
+    asg = [dict(distinct[i % 18]) for i in range(70)]
+    asg[7]["Sum"] = list(asg[7]["Sum"])
     asg[7]["Sum"][0] = (asg[7]["Sum"][0] + 1) % H.R
     status = _prove_and_check(zk_ctx, cc, asg, 4, wbits=(6, 4))
     assert list(status != 0) == [i == 7 for i in range(70)]
