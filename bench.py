@@ -68,9 +68,14 @@ def host_cpus():
 # one process already computed.  Files are this program's own output (pickle / .npy), written
 # atomically; a flock per file makes exactly one process compute each of them.
 def cache_dir():
+    """Private to this user: the compiled circuit is a pickle, and a pickle is only loaded from a
+    directory nobody else can write to (mode 0700, owned by us); anything else disables the cache."""
     d = os.environ.get("ZKMI_CACHE_DIR") or os.path.join(
         os.environ.get("TMPDIR", "/tmp"), f"zkmi-cache-{os.getuid()}")
-    os.makedirs(d, exist_ok=True)
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise PermissionError(f"{d}: not owned by this user or writable by others")
     return d
 
 
@@ -93,7 +98,10 @@ def cached(name, make, load, save, use_cache=True):
     if not use_cache:
         return make(), False
     import fcntl
-    path = os.path.join(cache_dir(), name)
+    try:
+        path = os.path.join(cache_dir(), name)
+    except (PermissionError, OSError):
+        return make(), False
     if os.path.exists(path):
         try:
             return load(path), True

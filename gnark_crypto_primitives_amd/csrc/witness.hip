@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256) void r1cs_eval_kernel(R1csDev m, const Fr* __r
                                                         Fr* __restrict__ a, Fr* __restrict__ b,
                                                         Fr* __restrict__ c, int32_t* __restrict__ st,
                                                         size_t Bp) {
-  const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (k >= m.n_constraints) return;
   const size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  // gridDim.y is capped (65 535 is the hardware limit): a block walks its rows with that stride
+  for (uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+       k < m.n_constraints; k += gridDim.y * 4) {
   Fr acc[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void r1cs_eval_kernel(R1csDev m, const Fr* __r
   bi_st(b, k, p, Bp, acc[1]);
   bi_st(c, k, p, Bp, acc[2]);
   if (mul(acc[0], acc[1]) != acc[2]) st[p] = ZKMI_ERR_UNSATISFIED;
+  }
 }
 
 }  // namespace zk
@@ -442,7 +444,8 @@ int zkmi_prove_witness_submit(zkmi_ctx* ctx, const zkmi_pk* pk, const zkmi_r1cs*
     }
     m.coeffs = r1cs->coeffs;
     m.n_constraints = r1cs->n_constraints;
-    hipLaunchKernelGGL(r1cs_eval_kernel, dim3((unsigned)(Bp / 64), (unsigned)((n_constraints + 3) / 4)),
+    hipLaunchKernelGGL(r1cs_eval_kernel,
+                       dim3((unsigned)(Bp / 64), (unsigned)std::min<size_t>((n_constraints + 3) / 4, 32768)),
                        dim3(256), 0, ctx->stream, m, (const Fr*)S.slots, (Fr*)S.a, (Fr*)S.b, (Fr*)S.c,
                        (int32_t*)S.st, Bp);
     if (hipGetLastError() != hipSuccess) rc = ZKMI_ERR_HIP;
