@@ -18,6 +18,10 @@
 #include "zkmi_internal.h"
 #include "sha256.h"
 #include <cstring>
+#include "ff29.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "ff29_asm.h"
+#endif
 
 using namespace zk;
 
@@ -40,6 +44,39 @@ struct zkmi_plonk_pk {
 namespace zk {
 
 #define LANE const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x
+
+// Products of the element-wise kernels on the 9 x 29-bit form (the single-accumulator asm chain of
+// ff29_asm.h: ~365 instructions with unpack and canonical pack, ~540 for ff.h's mul).  The chain
+// computes a b 2^-261 where ff.h's mul computes a b 2^-256, so exponents are tracked instead of
+// converting data: write im_e(x) = x 2^e mod r (gnark's image is e = 256); then
+//     fmulp(im_e1(x), im_e2(y)) = im_(e1 + e2 - 261)(x y),
+// sums need equal exponents, and every key-side operand is stored (plonk_pk_load) or every per-proof
+// scalar converted once (fmulp by the constant 2^(e' - e + 261)) with the exponent that makes the
+// result come out at 256 again.  Each kernel's comments carry the exponents.
+__device__ __forceinline__ Fr fmulp(const Fr& a, const Fr& b) {
+  Fr r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  pack_canonical<Fr29Params>(r.v, mul_asm(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
+#else
+  r = a;   // device-only helper
+#endif
+  return r;
+}
+// 2^e mod r as a canonical integer, e >= 256: Fr::one() doubled e - 256 times (host)
+// x 2^k by doublings: im_e(x) -> im_(e + k)(x)
+__host__ __device__ static inline Fr lift(Fr x, int k) {
+  for (int i = 0; i < k; i++) x = add(x, x);
+  return x;
+}
+__global__ void plonk_lift_kernel(Fr* x, size_t count, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) x[i] = lift(x[i], k);
+}
+static Fr pow2_image(int e) {
+  Fr x = Fr::one();
+  for (int i = 256; i < e; i++) x = add(x, x);
+  return x;
+}
 
 // cf[j] -= b_j, cf[n + j] += b_j: adds (b_(nb-1) X^(nb-1) + ... + b_0)(X^n - 1); the blinding rows
 // of `blind` are ordered highest power first (b1 X + b2 -> rows r0, r0 + 1)
@@ -127,14 +164,20 @@ __global__ __launch_bounds__(64) void plonk_z_fill(const Fr* ratio, const Fr* cp
 
 // quotient on the coset: T[j] = (gate + alpha (p1 - p2) + alpha^2 (z - 1) L1) / Z_H
 // key-side arrays (`ks`: qL, qR, qO, qM, qC, S1, S2, S3 on the coset, 4n each) are wave-uniform
-__global__ __launch_bounds__(64) void plonk_quotient(const Fr* ea, const Fr* eb, const Fr* ec,
+__global__ __launch_bounds__(64, 2) void plonk_quotient(const Fr* ea, const Fr* eb, const Fr* ec,
                                                      const Fr* ez, const Fr* epi, const Fr* ks,
                                                      const Fr* xs, const Fr* l1, const Fr* zh_inv,
                                                      const Fr* ch, Fr* T, size_t m, size_t Bp,
-                                                     Fr k1, Fr k2, int n_pub_direct) {
+                                                     Fr k1, Fr k2, int n_pub_direct, Fr c271,
+                                                     Fr c281) {
+  // exponents (fmulp above): per-proof data a, b, c, z, pub, beta, gamma, alpha: 256.  Key side as
+  // stored by zkmi_plonk_pk_load: qL qR qO S1 S2 S3 (ks rows 0 1 2 5 6 7), xs, l1, zh_inv, k1 = 5,
+  // k2 = 25: 261; qM (ks row 3): 266; qC (row 4): 256.
   LANE;
   const Fr beta = bi_ld(ch, 0, lane, Bp), gamma = bi_ld(ch, 1, lane, Bp),
            alpha = bi_ld(ch, 2, lane, Bp);
+  const Fr al2 = fmulp(fmulp(alpha, alpha), c271);   // alpha^2: 251 -> 261
+  const Fr al_x = fmulp(alpha, c281);                 // alpha: 276, for the 241 of p1 - p2
   // n_pub_direct >= 0: `epi` holds the public inputs x_t themselves (rows 0 .. n_pub - 1) and PI on
   // the coset is evaluated in closed form: L_t(x) = L_0(x / w^t) and x_j / w^t = x_(j - 4t) on the
   // coset 5 <w_4n>, so PI(x_j) = - sum_t x_t L1[j - 4t] -- no transform for a handful of inputs
@@ -143,24 +186,27 @@ __global__ __launch_bounds__(64) void plonk_quotient(const Fr* ea, const Fr* eb,
   for (size_t j = blockIdx.y; j < m; j += gridDim.y) {
     const Fr a = bi_ld(ea, j, lane, Bp), b = bi_ld(eb, j, lane, Bp), c = bi_ld(ec, j, lane, Bp),
              z = bi_ld(ez, j, lane, Bp), zw = bi_ld(ez, (j + 4) & (m - 1), lane, Bp);
-    Fr gate = add(add(mul(ks[j], a), mul(ks[m + j], b)), mul(ks[2 * m + j], c));
+    Fr gate = add(add(fmulp(ks[j], a), fmulp(ks[m + j], b)), fmulp(ks[2 * m + j], c));   // 256
     Fr pi;
     if (n_pub_direct >= 0) {
       pi = Fr::zero();
-      for (int t = 0; t < n_pub_direct; t++) pi = sub(pi, mul(pub[t], l1[(j - 4 * (size_t)t) & (m - 1)]));
+      for (int t = 0; t < n_pub_direct; t++)
+        pi = sub(pi, fmulp(pub[t], l1[(j - 4 * (size_t)t) & (m - 1)]));                 // 256
     } else {
       pi = bi_ld(epi, j, lane, Bp);
     }
-    gate = add(add(gate, mul(ks[3 * m + j], mul(a, b))), add(ks[4 * m + j], pi));
-    const Fr bx = mul(beta, xs[j]);
+    gate = add(add(gate, fmulp(ks[3 * m + j], fmulp(a, b))), add(ks[4 * m + j], pi));  // 266 + 251 -> 256
+    const Fr bx = fmulp(beta, xs[j]);                                                     // 256
     const Fr ag = add(a, gamma), bg = add(b, gamma), cg = add(c, gamma);
-    const Fr p1 = mul(mul(mul(add(ag, bx), add(bg, mul(bx, k1))), add(cg, mul(bx, k2))), z);
-    const Fr p2 = mul(mul(mul(add(ag, mul(beta, ks[5 * m + j])), add(bg, mul(beta, ks[6 * m + j]))),
-                          add(cg, mul(beta, ks[7 * m + j]))),
-                      zw);
-    const Fr t3 = mul(mul(mul(alpha, alpha), sub(z, Fr::one())), l1[j]);
-    const Fr num = add(add(gate, mul(alpha, sub(p1, p2))), t3);
-    bi_st(T, j, lane, Bp, mul(num, zh_inv[j & 3]));
+    // three 256 factors and z: 251, 246, 241
+    const Fr p1 = fmulp(fmulp(fmulp(add(ag, bx), add(bg, fmulp(bx, k1))), add(cg, fmulp(bx, k2))), z);
+    const Fr p2 = fmulp(fmulp(fmulp(add(ag, fmulp(beta, ks[5 * m + j])),
+                                    add(bg, fmulp(beta, ks[6 * m + j]))),
+                              add(cg, fmulp(beta, ks[7 * m + j]))),
+                        zw);
+    const Fr t3 = fmulp(fmulp(al2, sub(z, Fr::one())), l1[j]);                           // 261, 256 -> 256
+    const Fr num = add(add(gate, fmulp(al_x, sub(p1, p2))), t3);                          // 276 + 241 -> 256
+    bi_st(T, j, lane, Bp, fmulp(num, zh_inv[j & 3]));
   }
 }
 
@@ -206,30 +252,38 @@ __global__ __launch_bounds__(64) void plonk_eval_combine(EvalArgs args, const Fr
 
 // numerators of the two openings.  sc rows: 0 qm, 1 ql, 2 qr, 3 qo, 4 s3, 5 z, 6 tlo, 7 tmid, 8 thi,
 // 9 c0 (constant term: r0 - sum_i v^i e_i), 10 v, 11 zeta, 12 zeta*w, 13 z(zeta w)
-__global__ __launch_bounds__(64) void plonk_lin(const Fr* ca, const Fr* cb, const Fr* cc,
+__global__ __launch_bounds__(64, 2) void plonk_lin(const Fr* ca, const Fr* cb, const Fr* cc,
                                                 const Fr* cz, const Fr* t, const Fr* kc,
-                                                const Fr* sc, Fr* N, Fr* NZ, size_t n, size_t Bp) {
+                                                const Fr* sc, Fr* N, Fr* NZ, size_t n, size_t Bp,
+                                                Fr c266) {
+  // every product is (per-proof scalar) x (coefficient at 256): the scalars are lifted to 261 once
+  // per lane (fmulp by 2^266: 256 + 266 - 261), the products then land at 256 (see fmulp)
   LANE;
   const Fr v = bi_ld(sc, 10, lane, Bp);
-  const Fr v2 = mul(v, v), v3 = mul(v2, v), v4 = mul(v3, v), v5 = mul(v4, v);
-  const Fr sqm = bi_ld(sc, 0, lane, Bp), sql = bi_ld(sc, 1, lane, Bp), sqr_ = bi_ld(sc, 2, lane, Bp),
-           sqo = bi_ld(sc, 3, lane, Bp), ss3 = bi_ld(sc, 4, lane, Bp), sz = bi_ld(sc, 5, lane, Bp),
-           stl = bi_ld(sc, 6, lane, Bp), stm = bi_ld(sc, 7, lane, Bp), sth = bi_ld(sc, 8, lane, Bp);
+  const Fr vF = fmulp(v, c266);
+  const Fr v2 = fmulp(vF, v), v3 = fmulp(vF, v2), v4 = fmulp(vF, v3), v5 = fmulp(vF, v4);   // 256
+  const Fr v2F = fmulp(v2, c266), v3F = fmulp(v3, c266), v4F = fmulp(v4, c266), v5F = fmulp(v5, c266);
+#define SCF(row) fmulp(bi_ld(sc, (row), lane, Bp), c266)
+  const Fr sqm = SCF(0), sql = SCF(1), sqr_ = SCF(2), sqo = SCF(3), ss3 = SCF(4), sz = SCF(5),
+           stl = SCF(6), stm = SCF(7), sth = SCF(8);
+#undef SCF
   const size_t L = n + 3;
   for (size_t i = blockIdx.y; i < L; i += gridDim.y) {
     Fr r = Fr::zero();
     if (i < n) {   // key polynomials: qL qR qO qM qC S1 S2 S3 coefficient forms, n each
-      r = add(add(mul(sql, kc[i]), mul(sqr_, kc[n + i])), add(mul(sqo, kc[2 * n + i]), mul(sqm, kc[3 * n + i])));
-      r = add(r, add(kc[4 * n + i], mul(ss3, kc[7 * n + i])));
-      r = add(r, add(mul(v4, kc[5 * n + i]), mul(v5, kc[6 * n + i])));
+      r = add(add(fmulp(sql, kc[i]), fmulp(sqr_, kc[n + i])),
+              add(fmulp(sqo, kc[2 * n + i]), fmulp(sqm, kc[3 * n + i])));
+      r = add(r, add(kc[4 * n + i], fmulp(ss3, kc[7 * n + i])));
+      r = add(r, add(fmulp(v4F, kc[5 * n + i]), fmulp(v5F, kc[6 * n + i])));
     }
     const Fr zi = bi_ld(cz, i, lane, Bp);
-    r = add(r, mul(sz, zi));
+    r = add(r, fmulp(sz, zi));
     if (i < n + 2) {
-      r = add(r, add(mul(stl, bi_ld(t, i, lane, Bp)),
-                     add(mul(stm, bi_ld(t, n + 2 + i, lane, Bp)), mul(sth, bi_ld(t, 2 * n + 4 + i, lane, Bp)))));
-      r = add(r, add(mul(v, bi_ld(ca, i, lane, Bp)),
-                     add(mul(v2, bi_ld(cb, i, lane, Bp)), mul(v3, bi_ld(cc, i, lane, Bp)))));
+      r = add(r, add(fmulp(stl, bi_ld(t, i, lane, Bp)),
+                     add(fmulp(stm, bi_ld(t, n + 2 + i, lane, Bp)),
+                         fmulp(sth, bi_ld(t, 2 * n + 4 + i, lane, Bp)))));
+      r = add(r, add(fmulp(vF, bi_ld(ca, i, lane, Bp)),
+                     add(fmulp(v2F, bi_ld(cb, i, lane, Bp)), fmulp(v3F, bi_ld(cc, i, lane, Bp)))));
     }
     if (i == 0) r = add(r, bi_ld(sc, 9, lane, Bp));
     bi_st(N, i, lane, Bp, r);
@@ -365,6 +419,23 @@ int zkmi_plonk_pk_load(zkmi_ctx* ctx, const zkmi_plonk_pk_desc* d, zkmi_plonk_pk
     if (!u.src || hipMalloc((void**)u.dst, u.count * 32) != hipSuccess ||
         hipMemcpy(*u.dst, u.src, u.count * 32, hipMemcpyDefault) != hipSuccess) {
       ctx->err = "plonk pk: upload failed";
+      zkmi_plonk_pk_free(ctx, pk);
+      return ZKMI_ERR_HIP;
+    }
+  }
+  // exponents the quotient kernel expects (plonk_quotient): 2^261 images of qL qR qO S1 S2 S3 on the
+  // coset, of the coset points, L_1 and 1 / Z_H; 2^266 of qM; qC as uploaded
+  {
+    struct { Fr* p; size_t count; int k; } lifts[7] = {
+        {pk->coset, 3 * m, 5},   {pk->coset + 3 * m, m, 10}, {pk->coset + 5 * m, 3 * m, 5},
+        {pk->coset_x, m, 5},     {pk->l1, m, 5},             {pk->zh_inv, 4, 5},
+        {nullptr, 0, 0}};
+    for (auto& l : lifts)
+      if (l.count)
+        hipLaunchKernelGGL(plonk_lift_kernel, dim3((unsigned)((l.count + 255) / 256)), dim3(256), 0,
+                           ctx->stream, l.p, l.count, l.k);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      ctx->err = "plonk pk: key scaling failed";
       zkmi_plonk_pk_free(ctx, pk);
       return ZKMI_ERR_HIP;
     }
@@ -637,7 +708,8 @@ int zkmi_plonk_round3(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* alpha, void*
   Fr* T = (Fr*)pk->big[0].p;
   hipLaunchKernelGGL(plonk_quotient, dim3((unsigned)(Bp / 64), (unsigned)(m < 8192 ? m : 8192)),
                      dim3(64), 0, ctx->stream, EA, EB, EC, EZ, EPI, pk->coset, pk->coset_x, pk->l1,
-                     pk->zh_inv, ch, T, m, Bp, fr_small(5), fr_small(25), n_pub_direct);
+                     pk->zh_inv, ch, T, m, Bp, lift(fr_small(5), 5),
+                     lift(fr_small(25), 5), n_pub_direct, pow2_image(271), pow2_image(281));
   ZK_HIP(hipGetLastError());
   // coset interpolation: t coefficients in big[1]
   Fr* ct = (Fr*)pk->big[1].p;
@@ -721,7 +793,7 @@ int zkmi_plonk_round5(zkmi_ctx* ctx, zkmi_plonk_pk* pk, const void* scalars, voi
   hipLaunchKernelGGL(plonk_lin, dim3((unsigned)(Bp / 64), (unsigned)(L < 4096 ? L : 4096)),
                      dim3(64), 0, ctx->stream, (const Fr*)pk->cf[0].p, (const Fr*)pk->cf[1].p,
                      (const Fr*)pk->cf[2].p, (const Fr*)pk->cf[3].p, (const Fr*)pk->big[1].p,
-                     (const Fr*)pk->coef, (const Fr*)sc, N, NZ, n, Bp);
+                     (const Fr*)pk->coef, (const Fr*)sc, N, NZ, n, Bp, pow2_image(266));
   hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, W, L - 1,
                      n + 8, Bp);
   hipLaunchKernelGGL(plonk_zero_rows, dim3((unsigned)(Bp / 64), 8), dim3(64), 0, ctx->stream, WZ,
