@@ -138,3 +138,30 @@ class AddressCircuitByteTables(AddressCircuit):
     checks, one Groth16 commitment behind all of them (std/sha3.py::permute_bytes, std/uints.py,
     std/logderivprecomp.py)."""
     byte_tables = True
+
+
+class EmulatedPoseidonCircuit:
+    """hashCircuit of hash/emulated/bn254/poseidon/poseidon_test.go:17-33: Poseidon of three
+    emulated BN254 scalars (4 x 64-bit limbs each) equals the public emulated element -- every field
+    operation a product check of std/math/emulated (std/emulated.py), one Groth16 commitment behind
+    the range checks and the checks' challenge."""
+    Expected = Public(4)
+    In0 = Secret(4)
+    In1 = Secret(4)
+    In2 = Secret(4)
+
+    def define(self, api):
+        from .hash import emulated_poseidon as ep
+        from .std import emulated
+        f = emulated.NewField(api, ep.ScalarField)
+        ins = [emulated.Element(v, ep.ScalarField) for v in (self.In0, self.In1, self.In2)]
+        f.AssertIsEqual(ep.Hash(api, *ins), emulated.Element(self.Expected, ep.ScalarField))
+
+    @staticmethod
+    def assignment(ins, expected=None):
+        from .hash import poseidon_native
+        from .hash.emulated_poseidon import ScalarField as sf
+        from .std.emulated import ValueOf
+        e = poseidon_native.hash(list(ins)) if expected is None else expected
+        return {"Expected": ValueOf(e, sf), "In0": ValueOf(ins[0], sf), "In1": ValueOf(ins[1], sf),
+                "In2": ValueOf(ins[2], sf)}

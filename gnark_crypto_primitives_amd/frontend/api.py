@@ -40,8 +40,17 @@ OP_HIST, OP_HQ, OP_COMMIT = 20, 21, 22
 # bitwise XOR / AND of two small integers (< 2^32): the result hints of gnark's byte lookup tables
 # (std/internal/logderivprecomp: uints.Xor / And); unconstrained, the lookup constrains them
 OP_BXOR, OP_BAND = 23, 24
+# quotient and remainder of a product of two multi-limb integers by a 4 x 64-bit modulus (the mulHint
+# of gnark's std/math/emulated): a unit like OP_HIST,
+#   (OP_EMUL, first value, na + nb, nout | na << 8 | first const of the modulus << 12)
+#   + na + nb x (OP_HQ, 0, limb value, 0): the limbs of a, then of b, least significant first
+# a = sum a_i 2^(64 i), b likewise, p = sum const[first + i] 2^(64 i), i < 4: the nout - 4 64-bit limbs
+# of floor(a b / p), then the four of a b mod p, into consecutive wires
+OP_EMUL = 25
+EMUL_LIMB_BITS, EMUL_LIMBS = 64, 4
 
-HINT_INVZERO, HINT_NBITS, HINT_LIMBS, HINT_COUNT, HINT_COMMIT, HINT_BYTEOP = 1, 2, 3, 4, 5, 6
+HINT_INVZERO, HINT_NBITS, HINT_LIMBS, HINT_COUNT, HINT_COMMIT, HINT_BYTEOP, HINT_EMUL = \
+    1, 2, 3, 4, 5, 6, 7
 FIELD_BITS = 254      # bit length of r
 
 
@@ -609,6 +618,67 @@ class API:
         self.hints.append((HINT_COUNT, [{0: table_size}] + [q.lc for q in qs], wires))
         self.instr.append((1, len(self.hints) - 1))
         return [Variable({w: 1}, v) for w, v in zip(wires, vals)]
+
+    def NewHintEmulMul(self, a_limbs, b_limbs, modulus, n_quotient_limbs):
+        """Unconstrained hint (std/math/emulated mulHint [UPSTREAM-RECALL]): for the integers
+        a = sum a_i 2^(64 i) and b = sum b_i 2^(64 i) (limbs may exceed 64 bits: lazy additions) and
+        the modulus p < 2^256, fresh internal wires holding
+            k: the ``n_quotient_limbs`` 64-bit limbs of floor(a b / p),
+            r: the four 64-bit limbs of a b mod p,
+            c: the carries of  a(X) b(X) - r(X) - k(X) p(X) = (2^64 - X) c(X)  (signed, as field
+               elements; max(na + nb, nk + 4) - 2 of them).
+        Every limb product must stay below the field size (the caller bounds the overflows).
+        Witness side: k and r come from one OP_EMUL unit (big-integer division in the solver); the
+        carries are field arithmetic on the limbs, c_j = (t_j - r_j - (k p)_j + c_(j-1)) / 2^64."""
+        a_limbs = [self._v(x) for x in a_limbs]
+        b_limbs = [self._v(x) for x in b_limbs]
+        na, nb, nk, nr = len(a_limbs), len(b_limbs), int(n_quotient_limbs), EMUL_LIMBS
+        if not (1 <= na <= 4 and 1 <= nb <= 4 and 1 <= nk <= 8) or not 0 < modulus < 1 << 256:
+            raise CompileError("emulated product hint: 1..4 limbs per operand, 1..8 quotient limbs")
+        p_limbs = [(modulus >> (64 * i)) & (2**64 - 1) for i in range(nr)]
+        # the modulus' limbs sit in consecutive constants (appended together: _cid only shares)
+        cache = self.__dict__.setdefault("_emul_moduli", {})
+        first_c = cache.get(modulus)
+        if first_c is None:
+            first_c = cache[modulus] = len(self.const_list)
+            for i, pl in enumerate(p_limbs):
+                self.const_list.append(pl)
+                self.consts.setdefault(pl, first_c + i)
+        if first_c + nr > 1 << 20:
+            raise CompileError("constant pool too large for an emulated-product unit")
+        nout = nk + nr
+        first = self._new_val()
+        vals = [first] + [self._new_val() for _ in range(nout - 1)]
+        self.ops.append((OP_EMUL, first, na + nb, nout | na << 8 | first_c << 12))
+        for x in a_limbs + b_limbs:
+            self.ops.append((OP_HQ, 0, x.val, 0))
+        wires = [self._new_wire(v) for v in vals]
+        k = [Variable({w: 1}, v) for w, v in zip(wires[:nk], vals[:nk])]
+        r = [Variable({w: 1}, v) for w, v in zip(wires[nk:], vals[nk:])]
+        # carries: plain value arithmetic (no constraints)
+        ncols = max(na + nb - 1, nk + nr - 1)
+        inv64 = self._cid(pow(1 << 64, -1, R))
+        kp = [self.Sum([self._mul2(k[i], p_limbs[j - i]) for i in range(nk)
+                        if 0 <= j - i < nr and p_limbs[j - i]]) for j in range(ncols)]
+        carries, prev = [], None
+        for j in range(ncols - 1):
+            t = None
+            for i in range(na):
+                if 0 <= j - i < nb:
+                    m = self._emit(OP_MUL, a_limbs[i].val, b_limbs[j - i].val)
+                    t = m if t is None else self._emit(OP_ADD, t, m)
+            sub = self.Add(r[j], kp[j]) if j < nr else kp[j]
+            d = self._emit(OP_SUB, t, sub.val) if t is not None else self._emit(OP_NEG, sub.val)
+            if prev is not None:
+                d = self._emit(OP_ADD, d, prev)
+            prev = self._emit(OP_MULC, d, inv64)
+            carries.append(prev)
+        c_wires = [self._new_wire(v) for v in carries]
+        c = [Variable({w: 1}, v) for w, v in zip(c_wires, carries)]
+        self.hints.append((HINT_EMUL, [{0: na | nb << 8 | nk << 16}] + [x.lc for x in a_limbs + b_limbs] +
+                           [{0: pl} if pl else {} for pl in p_limbs], wires + c_wires))
+        self.instr.append((1, len(self.hints) - 1))
+        return k, r, c
 
     def Commit(self, *vs):
         """frontend.Committer.Commit (gnark r1cs builder, Groth16 commitment extension

@@ -14,7 +14,7 @@ import hashlib
 import numpy as np
 
 from .api import (API, HINT_INVZERO, HINT_NBITS, OP_ABC, OP_ADD, OP_ADDC, OP_BAND, OP_BATCHINV,
-                  OP_BITS, OP_BXOR, OP_COMMIT, OP_COPY, OP_DIV, OP_END, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC,
+                  OP_BITS, OP_BXOR, OP_COMMIT, OP_COPY, OP_DIV, OP_EMUL, OP_END, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC,
                   OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_XOR, OP_XORABC,
                   OP_SUB, R)
 
@@ -72,6 +72,19 @@ def from_mont_array(a: np.ndarray):
 SUB_LANE_CHOICES = (1, 2, 4, 8, 16)
 
 
+def emul_unit(limbs, aux, consts):
+    """What an OP_EMUL unit computes (api.py): limbs = the na limbs of a then the nb of b, aux =
+    nout | na << 8 | first modulus constant << 12.  Returns the nout - 4 quotient limbs and the four
+    remainder limbs (64 bits each)."""
+    nout, na, c0 = aux & 0xff, (aux >> 8) & 0xf, aux >> 12
+    a = sum(v << (64 * i) for i, v in enumerate(limbs[:na]))
+    b = sum(v << (64 * i) for i, v in enumerate(limbs[na:]))
+    p = sum(consts[c0 + i] << (64 * i) for i in range(4))
+    k, rem = divmod(a * b, p)
+    m = (1 << 64) - 1
+    return [(k >> (64 * i)) & m for i in range(nout - 4)] + [(rem >> (64 * i)) & m for i in range(4)]
+
+
 def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     """Scheduled (VLIW) form of a witness program: the operations packed into steps of up to S
     independent operations of one class, S sub-lanes per proof (schedule.py).
@@ -104,7 +117,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     for t, (c, idxs) in enumerate(steps):
         for i in idxs:
             op, dst, a, b = ops[i][:4]
-            if op in (OP_BATCHINV, OP_HIST, OP_COMMIT):
+            if op == OP_BATCHINV or op in sch.UNIT_HQ:
                 for q in range(1, sch.n_rows_of(ops[i]) + 1):
                     last[ops[i + q][2]] = t
             else:
@@ -154,7 +167,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
                         if d2 not in last:
                             released.append(slot[d2])
                 continue
-            if op in (OP_ABC, OP_BITS, OP_HIST, OP_COMMIT):
+            if op in (OP_ABC, OP_BITS) or op in sch.UNIT_HQ:
                 continue
             if dst not in slot:
                 if free:
@@ -176,7 +189,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
                 chunk = pairs[r * S:(r + 1) * S]
                 rows.append([(sch.CLS_BINV | 0x100, len(chunk), 0, 0)] + chunk +
                             [(0, 0, 0, 0)] * (S - len(chunk)))
-        elif c in (sch.CLS_HIST, sch.CLS_COMMIT):
+        elif c in (sch.CLS_HIST, sch.CLS_COMMIT, sch.CLS_EMUL):
             # class field of the quads = 0: the kernel takes the class from the header quad.
             # HIST: header (class, n queries, n rows, table size), quad 0 = (OP_HIST, first slot);
             # then ceil(n / S) rows of (OP_HQ, 0, query slot, 0).  COMMIT: one row, header (class,
@@ -184,9 +197,10 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
             # host ends a kernel launch in front of it (zkmi_cs_load records the row).
             i = idxs[0]
             op, dst, n_q, aux = ops[i][:4]
-            if c == sch.CLS_HIST:
+            # EMUL: as HIST with quad 0 = (OP_EMUL, first slot, 0, nout | na << 8 | const << 12)
+            if c in (sch.CLS_HIST, sch.CLS_EMUL):
                 nrows = -(-n_q // S)
-                rows.append([(c, n_q, nrows, aux), (OP_HIST, slot[dst], 0, aux)] +
+                rows.append([(c, n_q, nrows, aux), (op, slot[dst], 0, aux)] +
                             [(0, 0, 0, 0)] * (S - 1))
                 qs = [(OP_HQ, 0, slot[ops[i + q][2]], 0) for q in range(1, n_q + 1)]
                 for r in range(nrows):
@@ -204,7 +218,7 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         for i in idxs:
             op, dst, a, b = ops[i][:4]
             srcs = [ops[i + q][2] for q in range(1, sch.n_rows_of(ops[i]) + 1)] \
-                if op in (OP_BATCHINV, OP_HIST, OP_COMMIT) else sch.reads_of(*ops[i])
+                if (op == OP_BATCHINV or op in sch.UNIT_HQ) else sch.reads_of(*ops[i])
             for v in set(srcs):
                 if last.get(v) == t and v not in val_wire and v in slot:
                     released.append(slot.pop(v))
@@ -304,7 +318,7 @@ class CompiledCircuit:
             elif op == OP_BITS:
                 keep[i] = True
                 live[a] = True
-            elif op in (OP_HIST, OP_COMMIT, OP_BATCHINV):
+            elif op in (OP_HIST, OP_COMMIT, OP_BATCHINV, OP_EMUL):
                 keep[i] = True
             elif op in (OP_HQ, OP_PAIR):
                 keep[i] = True
@@ -355,7 +369,7 @@ class CompiledCircuit:
                         n_slots += 1
                 prog[i] = (op, slot[dst], slot[a], 0)
                 continue
-            if op in (OP_HIST, OP_COMMIT):
+            if op in (OP_HIST, OP_COMMIT, OP_EMUL):
                 prog[i] = (op, slot[dst], a, b)         # dst wire-backed; a operand rows follow
                 continue
             if op == OP_HQ:
@@ -458,6 +472,14 @@ class CompiledCircuit:
                             s[first + s[x]] += 1
                     r += 1
                 continue
+            if cls == sch.CLS_EMUL:
+                first, aux, ins = quads[0][1], hdr[3], []
+                for _ in range(hdr[2]):
+                    ins.extend(s[x] for w0, d, x, _y in rows[r][1:] if w0 & 0x1f == OP_HQ)
+                    r += 1
+                for j, v in enumerate(emul_unit(ins, aux, C)):
+                    s[first + j] = v
+                continue
             if cls == sch.CLS_COMMIT:
                 s[quads[0][1]] = self._commit_value(hdr[3], s)
                 continue
@@ -530,11 +552,13 @@ class CompiledCircuit:
         a_, b_, c_ = [], [], []
         C = self.consts
         self.last_status = 0
-        hist = None
+        hist = emul = None
         for op, d, a, b in self.program.tolist():
             chk, op = op & 0x100, op & 0xff
             if op not in (OP_HQ, OP_HIST):
                 hist = None
+            if op not in (OP_HQ, OP_EMUL) and emul is not None:
+                emul = None
             if op == OP_MUL:
                 s[d] = s[a] * s[b] % R
             elif op == OP_ADD:
@@ -581,6 +605,15 @@ class CompiledCircuit:
                 hist = (d, b)
                 for k in range(b):
                     s[d + k] = 0
+            elif op == OP_EMUL:
+                emul = [d, b, a, []]                  # first slot, aux, rows still to come, limbs
+            elif op == OP_HQ and emul is not None:
+                emul[3].append(s[a])
+                emul[2] -= 1
+                if emul[2] == 0:
+                    for k, v in enumerate(emul_unit(emul[3], emul[1], C)):
+                        s[emul[0] + k] = v
+                    emul = None
             elif op == OP_HQ:
                 if hist is not None and s[a] < hist[1]:     # rows of an OP_COMMIT only order it
                     s[hist[0] + s[a]] += 1

@@ -24,6 +24,7 @@ rewritten, scheduled program against the sequential one.
 """
 from __future__ import annotations
 
+from .schedule import UNIT_HQ as sch_unit_hq, unit_outputs
 from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BATCHINV, OP_BITS, OP_COMMIT, OP_COPY, OP_DIV, OP_HIST,
                   OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC, OP_SUB, OP_XOR,
                   OP_XORABC, R)
@@ -176,14 +177,15 @@ def relinearize(ops, val_wire, consts, n_vals):
             for o in pairs:
                 depth[o[1]] = d0
             continue
-        if op in (OP_HIST, OP_COMMIT):
+        if op in sch_unit_hq:
             # operand rows: materialised values; the unit defines wire-backed values only
             rows = [use(ops[i + j][2]) for j in range(a)]
             i += a
             out.append((op, dst, a, b))
             out.extend((OP_HQ, 0, x, 0) for x in rows)
-            d = max([dep(x) for x in rows], default=0) + (4000 if op == OP_HIST else 20000)
-            for v in (range(dst, dst + b) if op == OP_HIST else (dst,)):
+            d = max([dep(x) for x in rows], default=0) + \
+                (4000 if op == OP_HIST else 20000 if op == OP_COMMIT else 1500)
+            for v in unit_outputs((op, dst, a, b)):
                 depth[v] = d
             continue
         if op == OP_ABC:

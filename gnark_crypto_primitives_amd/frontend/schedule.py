@@ -24,30 +24,43 @@ from __future__ import annotations
 import heapq
 
 from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BAND, OP_BATCHINV, OP_BITS, OP_BXOR, OP_COMMIT, OP_COPY,
-                  OP_DIV, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC,
+                  OP_DIV, OP_EMUL, OP_HIST, OP_HQ, OP_INV, OP_MUL, OP_MULABC, OP_MULC, OP_NEG, OP_PAIR, OP_SETC,
                   OP_SUB, OP_XOR, OP_XORABC)
 
 OP_FMAC, OP_FMA = 18, 19       # relin.py: (op, dst, x, const, addend) / (op, dst, x, y, addend)
-CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B = range(1, 11)
+CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B, CLS_EMUL = \
+    range(1, 12)
 # CLS_B (byte-op hints) is a scheduling class of its own -- a step never mixes them with inversions --
 # but runs in the kernel's CLS_I arm (its quads carry class CLS_I)
 # the class field of an operand quad has three bits: HIST / COMMIT rows carry 0 there and their
 # class in the header quad
-SINGLE = (CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT)
+SINGLE = (CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_EMUL)
+UNIT_HQ = (OP_HIST, OP_COMMIT, OP_EMUL)      # unit ops followed by o[2] OP_HQ operand rows
 CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_FMA: CLS_M, OP_XORABC: CLS_X, OP_XOR: CLS_X,
             OP_ADD: CLS_A, OP_SUB: CLS_A, OP_ADDC: CLS_A, OP_NEG: CLS_A, OP_COPY: CLS_A,
             OP_SETC: CLS_A, OP_ABC: CLS_R, OP_INV: CLS_I, OP_DIV: CLS_I, OP_BITS: CLS_BITS,
             OP_BATCHINV: CLS_BINV, OP_HIST: CLS_HIST, OP_COMMIT: CLS_COMMIT, OP_BXOR: CLS_B,
-            OP_BAND: CLS_B}
+            OP_BAND: CLS_B, OP_EMUL: CLS_EMUL}
 # relative time of one step of the class on a lone wavefront (instruction counts / 40)
 COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000,
-        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20}
+        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20, CLS_EMUL: 1500}
 
 
 def n_rows_of(o):
     """operand rows that follow a unit op (OP_PAIR rows of OP_BATCHINV, OP_HQ rows of OP_HIST /
     OP_COMMIT)"""
-    return o[1] if o[0] == OP_BATCHINV else o[2] if o[0] in (OP_HIST, OP_COMMIT) else 0
+    return o[1] if o[0] == OP_BATCHINV else o[2] if o[0] in UNIT_HQ else 0
+
+
+def unit_outputs(o):
+    """values a unit op with OP_HQ rows defines: the table's multiplicities (OP_HIST), the quotient
+    and remainder limbs (OP_EMUL: low byte of b), the challenge (OP_COMMIT)"""
+    op, dst, _a, b = o[:4]
+    if op == OP_HIST:
+        return range(dst, dst + b)
+    if op == OP_EMUL:
+        return range(dst, dst + (b & 0xff))
+    return (dst,)
 
 
 def bits_count(b):
@@ -86,8 +99,8 @@ def schedule(ops, n_bits_vals, S):
                 producer[ops[i + k][1]] = i
             i += dst + 1
             continue
-        if op in (OP_HIST, OP_COMMIT):
-            for v in (range(dst, dst + b) if op == OP_HIST else (dst,)):
+        if op in UNIT_HQ:
+            for v in unit_outputs(ops[i]):
                 producer[v] = i
             i += a + 1
             continue
@@ -101,7 +114,7 @@ def schedule(ops, n_bits_vals, S):
     npred = {u: 0 for u in units}
     for u in units:
         op, dst, a, b = ops[u][:4]
-        if op in (OP_BATCHINV, OP_HIST, OP_COMMIT):
+        if op == OP_BATCHINV or op in UNIT_HQ:
             rd = [ops[u + k][2] for k in range(1, n_rows_of(ops[u]) + 1)]
         else:
             rd = reads_of(*ops[u])

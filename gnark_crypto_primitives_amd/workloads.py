@@ -10,7 +10,7 @@ from .tree import smt_witness
 
 R = poseidon_native.R
 NAMES = ("arbo", "poseidon", "verifier", "elgamal-add", "elgamal-encrypt", "address",
-         "address-commit", "address-bytes")
+         "address-commit", "address-bytes", "emulated-poseidon")
 
 
 def _poseidon(rng):
@@ -83,4 +83,10 @@ def build(name, levels=160, populated=10):
         return (circuits.AddressCircuitByteTables(), _address,
                 "secp256k1 address derivation the way gnark compiles it: byte-wise Keccak-256 over "
                 "uints.U64 with XOR / AND lookup tables, one Groth16 commitment (config 5)")
+    if name == "emulated-poseidon":
+        return (circuits.EmulatedPoseidonCircuit(),
+                lambda rng: circuits.EmulatedPoseidonCircuit.assignment(
+                    [rng.randrange(R) for _ in range(3)]),
+                "Poseidon of three emulated BN254 scalars (hash/emulated/bn254/poseidon), "
+                "std/math/emulated product checks, one Groth16 commitment")
     raise ValueError(f"unknown workload {name!r}; one of {NAMES}")

@@ -67,6 +67,8 @@ def compiled(name):
         return compile_circuit(circuits.AddressCircuitCommit(), 16)
     if name == "address-bytes":
         return compile_circuit(circuits.AddressCircuitByteTables(), 16)
+    if name == "emulated-poseidon":
+        return compile_circuit(circuits.EmulatedPoseidonCircuit(), 16)
     if name == "address-scs":
         from gnark_crypto_primitives_amd.frontend.scs import compile_scs
         return compile_scs(compiled("address"))
