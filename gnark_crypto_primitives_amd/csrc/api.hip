@@ -876,9 +876,10 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
     return ZKMI_ERR_ARG;
   }
   // validate every slot / constant / row index on the host before anything reaches a kernel
-  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT };
-  enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24 };
+  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_EMUL = 11 };
+  enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24, OP_EMUL = 25 };
   std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
+  bool has_emul = false;
   const uint32_t* p = d->program;
   const size_t stride = (size_t)(1 + S) * 4;
   std::vector<uint8_t> row_seen(d->n_constraints, 0);
@@ -917,20 +918,30 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
       r += nrows;
       continue;
     }
-    if (cls == CLS_HIST) {
+    if (cls == CLS_HIST || cls == CLS_EMUL) {
       // header (class, n queries, n rows, table size), quad 0 = (OP_HIST, first counter wire);
-      // the rows that follow hold the query slots; every quad carries class 0
+      // the rows that follow hold the query slots; every quad carries class 0.
+      // CLS_EMUL: header (class, na + nb, n rows, aux), quad 0 = (OP_EMUL, first wire, 0, aux),
+      // aux = nout | na << 8 | first modulus constant << 12; rows: the limb slots of a, then of b
       const uint32_t nq = h[1], nrows = h[2], size = h[3];
       const uint32_t* q0 = h + 4;
-      if (q0[0] != OP_HIST || size == 0 || (uint64_t)q0[1] + size > d->n_wires ||
-          nrows != (nq + S - 1) / S || (uint64_t)r + nrows > (uint64_t)d->n_rows - 1)
-        return bad(r);
+      if (nrows != (nq + S - 1) / S || (uint64_t)r + nrows > (uint64_t)d->n_rows - 1) return bad(r);
+      if (cls == CLS_HIST) {
+        if (q0[0] != OP_HIST || size == 0 || (uint64_t)q0[1] + size > d->n_wires) return bad(r);
+      } else {
+        const uint32_t nout = size & 0xff, na = (size >> 8) & 0xf, c0 = size >> 12;
+        if (q0[0] != OP_EMUL || q0[3] != size || nout < 5 || nout > 12 || na < 1 || na > 4 ||
+            nq <= na || nq - na > 4 || (uint64_t)q0[1] + nout > d->n_wires ||
+            (uint64_t)c0 + 4 > d->n_consts)
+          return bad(r);
+        has_emul = true;
+      }
       for (uint32_t l = 1; l < S; l++)
         if (h[4 * (1 + l)] != 0) return bad(r);
       uint32_t seen = 0;
       for (uint32_t t = 1; t <= nrows; t++) {
         const uint32_t* hh = p + (size_t)(r + t) * stride;
-        if (hh[0] != (CLS_HIST | 0x100u)) return bad(r + t);
+        if (hh[0] != (cls | 0x100u)) return bad(r + t);
         for (uint32_t l = 0; l < S; l++) {
           const uint32_t* q = hh + 4 * (1 + l);
           if (q[0] == OP_END) {
@@ -1025,6 +1036,7 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   cs->n_consts = d->n_consts;
   cs->lanes_per_proof = S;
   cs->commit_rows = commit_rows;   // (row, commitment wire) in commitment order
+  cs->has_emul = has_emul;
   int rc = upload_u32(ctx, d->program, (size_t)d->n_rows * stride, &cs->program);
   if (rc) {
     delete cs;

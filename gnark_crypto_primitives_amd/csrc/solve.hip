@@ -84,11 +84,12 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // instruction, because the vector memory instructions of a wavefront reach the CU's L1 / the L2 in
 // issue order (a workgroup-scope fence here -- s_waitcnt vmcnt(0) after every step -- exposed the
 // store latency: 96 -> 7x ms per batch).
-enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT };
+enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B_UNUSED,
+       CLS_EMUL };
 // CLS_HIST / CLS_COMMIT do not fit the three class bits of an operand quad: their quads carry
 // class 0 and the class sits in the header quad.  OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22
 // (frontend/api.py).
-enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24 };
+enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24, OP_EMUL = 25 };
 
 // Stores of the hot step classes.  gfx950 reads the data registers of a vector store out of order
 // with later VGPR writes, so the compiler waits for a store to complete (s_waitcnt vmcnt) before it
@@ -148,7 +149,65 @@ __device__ __forceinline__ Fr ld_sel(const Fr* slots, const Fr* consts, uint32_t
   return r;
 }
 
-template <int S>
+// ---- OP_EMUL: big-integer division for the product hint of std/math/emulated (frontend/api.py) ----
+// Plain 32-bit word arrays with compile-time indices only (registers, no scratch): the limb offset of
+// an operand is wave-uniform, so the add-at-offset is a switch over four instances.
+template <int OFF>
+__device__ __forceinline__ void emul_acc(uint32_t (&X)[12], const Fr& v) {
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j + OFF < 12; j++) {
+    const uint64_t t = (uint64_t)X[OFF + j] + (j < 8 ? v.v[j] : 0u) + carry;
+    X[OFF + j] = (uint32_t)t;
+    carry = t >> 32;
+  }
+}
+__device__ __forceinline__ void emul_acc_at(uint32_t (&X)[12], const Fr& v, uint32_t limb) {
+  switch (limb) {
+    case 0: emul_acc<0>(X, v); break;
+    case 1: emul_acc<2>(X, v); break;
+    case 2: emul_acc<4>(X, v); break;
+    default: emul_acc<6>(X, v); break;
+  }
+}
+// T <- floor(T / P) (24 words), Rm <- T mod P (9 words): restoring division, one bit per step; the
+// quotient bits enter T from below while its bits leave at the top.  Leading words that are zero in
+// every active lane are skipped.  P = 0 only yields garbage (the host never builds such a unit).
+__device__ __forceinline__ void emul_divmod(uint32_t (&T)[24], uint32_t (&Rm)[9], const uint32_t (&P)[8]) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rm[i] = 0;
+  uint32_t words = 24;
+  while (words > 1 && __ballot(T[23] != 0) == 0) {
+#pragma unroll
+    for (int i = 23; i > 0; i--) T[i] = T[i - 1];
+    T[0] = 0;
+    words--;
+  }
+#pragma unroll 1
+  for (uint32_t it = 0; it < 32 * words; it++) {
+    const uint32_t top = T[23] >> 31;
+#pragma unroll
+    for (int i = 23; i > 0; i--) T[i] = (T[i] << 1) | (T[i - 1] >> 31);
+    T[0] <<= 1;
+#pragma unroll
+    for (int i = 8; i > 0; i--) Rm[i] = (Rm[i] << 1) | (Rm[i - 1] >> 31);
+    Rm[0] = (Rm[0] << 1) | top;
+    uint32_t D[9];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const uint64_t t = (uint64_t)Rm[i] - (i < 8 ? P[i] : 0u) - borrow;
+      D[i] = (uint32_t)t;
+      borrow = (t >> 32) & 1;
+    }
+    const bool ge = borrow == 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rm[i] = ge ? D[i] : Rm[i];
+    T[0] |= ge ? 1u : 0u;
+  }
+}
+
+template <int S, bool EMUL>
 __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict__ prog,
                                                         const Fr* __restrict__ consts, Fr* slots,
                                                         Fr* __restrict__ a, Fr* __restrict__ b,
@@ -395,6 +454,77 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           r += nrows;
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
+        if constexpr (EMUL) {
+          // CLS_EMUL: header (class, na + nb, n rows, aux), quad 0 = (OP_EMUL, first slot, 0, aux),
+          // aux = nout | na << 8 | first modulus constant << 12; the rows that follow hold the limb
+          // slots of a, then of b.  a = sum a_i 2^(64 i) (a limb may exceed 64 bits), b likewise,
+          // p = the four 64-bit constants: nout - 4 limbs of floor(a b / p), then four of a b mod p,
+          // into consecutive wires.  Sub-lane 0 works, as in CLS_HIST.
+          if ((hdr.x & 0xffu) == CLS_EMUL && !(hdr.x & 0x100u)) {
+            const uint4 q0 = prog[(size_t)r * (1 + S) + 1];
+            const uint32_t nq = __builtin_amdgcn_readfirstlane(hdr.y);
+            const uint32_t nrows = __builtin_amdgcn_readfirstlane(hdr.z);
+            const uint32_t aux = __builtin_amdgcn_readfirstlane(hdr.w);
+            const uint32_t nk = (aux & 0xffu) - 4, na = (aux >> 8) & 0xfu, c0 = aux >> 12;
+            if (sl == 0) {
+              uint32_t A[12], B[12], T[24], Rm[9], P[8];
+#pragma unroll
+              for (int i = 0; i < 12; i++) A[i] = B[i] = 0;
+              const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1;
+              for (uint32_t t = 0; t < nq; t++) {
+                const uint4 p = pr[(size_t)(t / S) * (1 + S) + (t % S)];
+                if ((p.x & 0x1fu) != OP_HQ) continue;
+                const Fr v = f_plain(LD(p.z));
+                if (t < na)
+                  emul_acc_at(A, v, t);
+                else
+                  emul_acc_at(B, v, t - na);
+              }
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const Fr v = f_plain(consts[c0 + i]);
+                P[2 * i] = v.v[0];
+                P[2 * i + 1] = v.v[1];
+              }
+#pragma unroll
+              for (int i = 0; i < 24; i++) T[i] = 0;
+#pragma unroll
+              for (int i = 0; i < 12; i++) {
+                uint64_t carry = 0;
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                  const uint64_t t = (uint64_t)A[i] * B[j] + T[i + j] + carry;
+                  T[i + j] = (uint32_t)t;
+                  carry = t >> 32;
+                }
+              }
+              emul_divmod(T, Rm, P);
+              constexpr uint32_t c522[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
+                                            0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};   // 2^522 mod r
+              Fr k522;
+#pragma unroll
+              for (int t = 0; t < 8; t++) k522.v[t] = c522[t];
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                if ((uint32_t)j < nk) {
+                  Fr pm = Fr::zero();
+                  pm.v[0] = T[2 * j];
+                  pm.v[1] = T[2 * j + 1];
+                  ST(q0.y + j, fmul(pm, k522));
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                Fr pm = Fr::zero();
+                pm.v[0] = Rm[2 * j];
+                pm.v[1] = Rm[2 * j + 1];
+                ST(q0.y + nk + j, fmul(pm, k522));
+              }
+            }
+            r += nrows;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+          }
+        }
         break;
       }
     }
@@ -490,8 +620,12 @@ int solve_rows(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c,
   const dim3 grid((unsigned)(Bp * S / 64)), block(64);
   const uint4* prog = (const uint4*)cs->program;
 #define ZK_SOLVE(SS)                                                                          \
-  hipLaunchKernelGGL((solve_vliw_kernel<SS>), grid, block, 0, ctx->stream, prog, cs->consts, \
-                     slots, a, b, c, status, Bp, cs->n_rows, row_begin, row_end)
+  if (cs->has_emul)                                                                               \
+    hipLaunchKernelGGL((solve_vliw_kernel<SS, true>), grid, block, 0, ctx->stream, prog,          \
+                       cs->consts, slots, a, b, c, status, Bp, cs->n_rows, row_begin, row_end);   \
+  else                                                                                            \
+    hipLaunchKernelGGL((solve_vliw_kernel<SS, false>), grid, block, 0, ctx->stream, prog,         \
+                       cs->consts, slots, a, b, c, status, Bp, cs->n_rows, row_begin, row_end)
   switch (S) {
     case 1: ZK_SOLVE(1); break;
     case 2: ZK_SOLVE(2); break;

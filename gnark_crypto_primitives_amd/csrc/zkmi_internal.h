@@ -170,6 +170,9 @@ struct zkmi_cs {
   // COMMIT rows of the program in order: (row index, commitment index); the solver kernel is
   // launched once per segment between them
   std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
+  // the program holds OP_EMUL units (std/math/emulated product hints): the solver variant with the
+  // big-integer division arm is launched
+  bool has_emul = false;
 };
 
 namespace zk {

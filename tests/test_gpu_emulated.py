@@ -1,0 +1,60 @@
+"""gnark ``std/math/emulated`` on the GPU: circuits over an emulated field are
+solved by the device solver -- the product hint's big-integer division runs in the OP_EMUL arm of
+solve_vliw_kernel<S, true> --, proved with the Groth16 commitment extension and compared bit for bit
+(proof, commitment, proof of knowledge, per-proof status) with the C oracle, whose solver has its own
+division (oracle/c/zkref_prove.inc, hint kind 7).  Reference users: hash/emulated/bn254/poseidon
+(its test: poseidon_test.go:45-78), tree/smt/emulated.  Parity unpinned (tests/test_emulated.py)."""
+import random
+
+import pytest
+
+from gnark_crypto_primitives_amd import circuits
+from gnark_crypto_primitives_amd.frontend import compile_circuit
+from gnark_crypto_primitives_amd.hash import poseidon_native
+from gnark_crypto_primitives_amd.std import emulated as em
+from tests import helpers as H
+from tests.test_emulated import ArithCircuit
+from tests.test_gpu_commitment import _check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("params,lanes", [(em.BN254Fr, 1), (em.BN254Fr, 4), (em.Secp256k1Fp, 2),
+                                          (em.Secp256k1Fp, 16), (em.BN254Fp, 8)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_emulated_arithmetic(zk_ctx, params, lanes):
+    circ = ArithCircuit(params)
+    cc = compile_circuit(circ, lanes)
+    p = params.modulus
+    rng = random.Random(lanes)
+    asg = [circ.assignment(rng.randrange(p), rng.randrange(p)) for _ in range(70)]
+    asg[1] = circ.assignment(p - 1, 1)
+    asg[2] = circ.assignment(0, 0)                  # x == y: flag 1, the select takes x
+    x = rng.randrange(p)
+    asg[3] = circ.assignment(x, x)
+    asg[4] = circ.assignment(p - 1, p - 1)
+    asg[9] = circ.assignment(x, 5, z=7)             # wrong product
+    asg[63] = circ.assignment(x, 6, flag=1)
+    asg[64] = circ.assignment(x, 7, s=x)            # wrong selected value
+    bad = [9, 63, 64]
+    limbs = list(asg[69]["X"])
+    limbs[2] += 1 << 64                              # a witness limb wider than 64 bits
+    asg[69] = dict(asg[69], X=limbs)
+    bad.append(69)
+    _check(zk_ctx, cc, asg, bad, 70 + lanes,
+           publics=[list(a["Z"]) + [a["Flag"]] for a in asg])
+
+
+def test_emulated_poseidon_matches_native(zk_ctx):
+    """The reference's TestEmulatedPoseidonMatchesNative (inputs 1, 2, 3) and random inputs: 122 734
+    constraints, 2^17 domain, ~8 * 10^2 product checks per proof."""
+    cc = H.compiled("emulated-poseidon")
+    assert cc.domain_log2() == 17 and len(cc.commitments) == 1
+    mk = circuits.EmulatedPoseidonCircuit.assignment
+    rng = random.Random(8)
+    asg = [mk((1, 2, 3)), mk((0, 0, 0)), mk((H.R - 1, H.R - 2, 1)),
+           mk([rng.randrange(H.R) for _ in range(3)]),
+           mk((1, 2, 3), poseidon_native.hash([1, 2, 4]))]
+    assert sum(v << (64 * i) for i, v in enumerate(asg[0]["Expected"])) == poseidon_native.hash([1, 2, 3])
+    _check(zk_ctx, cc, asg, [4], 81, wbits=(0, 0), publics=[list(a["Expected"]) for a in asg],
+           max_batch=64)

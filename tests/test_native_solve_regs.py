@@ -31,7 +31,9 @@ def test_solver_kernels_keep_the_accumulation_registers_to_themselves():
         m = re.search(r"remark:\s+(AGPRs|VGPRs Spill): (\d+)", line)
         if m and cur and "solve_vliw_kernel" in cur:
             seen.setdefault(cur, {})[m.group(1)] = int(m.group(2))
-    lanes = sorted(int(re.search(r"kernelILi(\d+)E", k).group(1)) for k in seen)
-    assert lanes == [1, 2, 4, 8, 16], lanes
+    # S sub-lanes x {without, with} the OP_EMUL arm (std/math/emulated product hints)
+    lanes = sorted((int(m.group(1)), int(m.group(2)))
+                   for m in (re.search(r"kernelILi(\d+)ELb(\d)E", k) for k in seen))
+    assert lanes == [(s, e) for s in (1, 2, 4, 8, 16) for e in (0, 1)], lanes
     for name, r in seen.items():
         assert r == {"AGPRs": 32, "VGPRs Spill": 0}, (name, r)
