@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "zkmi_internal.h"
+#include "emul.h"
 #include "ff29.h"
 #include "ff29_asm.h"
 #include "modinv30.h"
@@ -147,64 +148,6 @@ __device__ __forceinline__ Fr ld_sel(const Fr* slots, const Fr* consts, uint32_t
   r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
   r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
   return r;
-}
-
-// ---- OP_EMUL: big-integer division for the product hint of std/math/emulated (frontend/api.py) ----
-// Plain 32-bit word arrays with compile-time indices only (registers, no scratch): the limb offset of
-// an operand is wave-uniform, so the add-at-offset is a switch over four instances.
-template <int OFF>
-__device__ __forceinline__ void emul_acc(uint32_t (&X)[12], const Fr& v) {
-  uint64_t carry = 0;
-#pragma unroll
-  for (int j = 0; j + OFF < 12; j++) {
-    const uint64_t t = (uint64_t)X[OFF + j] + (j < 8 ? v.v[j] : 0u) + carry;
-    X[OFF + j] = (uint32_t)t;
-    carry = t >> 32;
-  }
-}
-__device__ __forceinline__ void emul_acc_at(uint32_t (&X)[12], const Fr& v, uint32_t limb) {
-  switch (limb) {
-    case 0: emul_acc<0>(X, v); break;
-    case 1: emul_acc<2>(X, v); break;
-    case 2: emul_acc<4>(X, v); break;
-    default: emul_acc<6>(X, v); break;
-  }
-}
-// T <- floor(T / P) (24 words), Rm <- T mod P (9 words): restoring division, one bit per step; the
-// quotient bits enter T from below while its bits leave at the top.  Leading words that are zero in
-// every active lane are skipped.  P = 0 only yields garbage (the host never builds such a unit).
-__device__ __forceinline__ void emul_divmod(uint32_t (&T)[24], uint32_t (&Rm)[9], const uint32_t (&P)[8]) {
-#pragma unroll
-  for (int i = 0; i < 9; i++) Rm[i] = 0;
-  uint32_t words = 24;
-  while (words > 1 && __ballot(T[23] != 0) == 0) {
-#pragma unroll
-    for (int i = 23; i > 0; i--) T[i] = T[i - 1];
-    T[0] = 0;
-    words--;
-  }
-#pragma unroll 1
-  for (uint32_t it = 0; it < 32 * words; it++) {
-    const uint32_t top = T[23] >> 31;
-#pragma unroll
-    for (int i = 23; i > 0; i--) T[i] = (T[i] << 1) | (T[i - 1] >> 31);
-    T[0] <<= 1;
-#pragma unroll
-    for (int i = 8; i > 0; i--) Rm[i] = (Rm[i] << 1) | (Rm[i - 1] >> 31);
-    Rm[0] = (Rm[0] << 1) | top;
-    uint32_t D[9];
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const uint64_t t = (uint64_t)Rm[i] - (i < 8 ? P[i] : 0u) - borrow;
-      D[i] = (uint32_t)t;
-      borrow = (t >> 32) & 1;
-    }
-    const bool ge = borrow == 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) Rm[i] = ge ? D[i] : Rm[i];
-    T[0] |= ge ? 1u : 0u;
-  }
 }
 
 template <int S, bool EMUL>
@@ -476,9 +419,9 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
                 if ((p.x & 0x1fu) != OP_HQ) continue;
                 const Fr v = f_plain(LD(p.z));
                 if (t < na)
-                  emul_acc_at(A, v, t);
+                  emul_acc_at(A, v.v, t);
                 else
-                  emul_acc_at(B, v, t - na);
+                  emul_acc_at(B, v.v, t - na);
               }
 #pragma unroll
               for (int i = 0; i < 4; i++) {
@@ -486,18 +429,7 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
                 P[2 * i] = v.v[0];
                 P[2 * i + 1] = v.v[1];
               }
-#pragma unroll
-              for (int i = 0; i < 24; i++) T[i] = 0;
-#pragma unroll
-              for (int i = 0; i < 12; i++) {
-                uint64_t carry = 0;
-#pragma unroll
-                for (int j = 0; j < 12; j++) {
-                  const uint64_t t = (uint64_t)A[i] * B[j] + T[i + j] + carry;
-                  T[i + j] = (uint32_t)t;
-                  carry = t >> 32;
-                }
-              }
+              emul_mul(T, A, B);
               emul_divmod(T, Rm, P);
               constexpr uint32_t c522[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
                                             0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};   // 2^522 mod r

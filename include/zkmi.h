@@ -196,7 +196,11 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
  *   a, b).  Systems with commitments hold one COMMIT row per commitment (header class 9, aux =
  *   commitment index): the solver stops in front of it, the prover commits, hashes, writes the
  *   challenge into the commitment wire and resumes (zkmi_prove_submit needs a key whose
- *   n_commitments matches). */
+ *   n_commitments matches).  Unit rows with operand rows behind them: multiplicities of a lookup
+ *   table (class 8: gnark std/lookup/logderivarg's count hint) and the quotient / remainder of a
+ *   multi-limb product by a 4 x 64-bit modulus (class 11: the mulHint of gnark's std/math/emulated;
+ *   header (11, na + nb, rows, nout | na << 8 | first modulus constant << 12), the limb slots of the
+ *   two operands in the rows that follow, nout consecutive wires written). */
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
   uint32_t n_slots, n_rows, n_consts;
