@@ -185,3 +185,67 @@ def test_emulated_poseidon_matches_native():
         cc.commit_fn = None
     rc, *_ = cref.r1cs_solve_ex(rh, ch, to_mont_array(bad))
     assert rc != 0
+
+
+# ---- ecc/format/twistededwards_test.go: native and emulated coordinate changes in one circuit -------
+FORMAT_X = 20284931487578954787250358776722960153090567235942462656834196519767860852891
+FORMAT_Y = 21185575020764391300398134415668786804224896114060668011215204645513129497221
+
+
+class FormatCircuit:
+    """testFromTwistedEdwards / testToTwistedEdwards (twistededwards_test.go:20-68)"""
+    X = Secret()
+    Y = Secret()
+    XPrime = Secret()
+    YPrime = Secret()
+    EX = Secret(4)
+    EY = Secret(4)
+    EXPrime = Secret(4)
+    EYPrime = Secret(4)
+
+    def __init__(self, to_te):
+        self.to_te = to_te
+
+    def define(self, api):
+        from gnark_crypto_primitives_amd.ecc import format as fmt
+        sf = em.BN254Fr
+        native, emulated_ = (fmt.FromRTEtoTE, fmt.FromEmulatedRTEtoTE) if self.to_te else \
+            (fmt.FromTEtoRTE, fmt.FromEmulatedTEtoRTE)
+        xp, yp = native(api, self.X, self.Y)
+        api.AssertIsEqual(xp, self.XPrime)
+        api.AssertIsEqual(yp, self.YPrime)
+        exp, eyp = emulated_(api, em.Element(self.EX, sf), em.Element(self.EY, sf))
+        field = em.NewField(api, sf)
+        field.AssertIsEqual(exp, em.Element(self.EXPrime, sf))
+        field.AssertIsEqual(eyp, em.Element(self.EYPrime, sf))
+
+
+def format_assignment(to_te, x=FORMAT_X, y=FORMAT_Y, bad=False):
+    from gnark_crypto_primitives_amd.ecc import format as fmt
+    xr, yr = fmt.te_to_rte_native(x, y)
+    src, dst = ((xr, yr), (x, y)) if to_te else ((x, y), (xr, yr))
+    v = lambda n: em.ValueOf(n, em.BN254Fr)
+    return {"X": src[0], "Y": src[1], "XPrime": dst[0], "YPrime": dst[1], "EX": v(src[0]),
+            "EY": v(src[1]), "EXPrime": v(dst[0] + (1 if bad else 0)), "EYPrime": v(dst[1])}
+
+
+@pytest.mark.parametrize("to_te", [False, True], ids=["TEtoRTE", "RTEtoTE"])
+def test_format_native_and_emulated(to_te):
+    """TestFromTwistedEdwards / TestFromReducedTwistedEdwards (twistededwards_test.go:70-134): the
+    reference's point, converted natively and over the emulated field; the limb constants of
+    twistededwards.go:18-23 are -f and its inverse."""
+    from gnark_crypto_primitives_amd.ecc import format as fmt
+    limbs = lambda ls: sum(int(v) << (64 * i) for i, v in enumerate(ls))
+    assert limbs(fmt.EMULATED_NEG_SCALING_FACTOR) == -fmt.SCALING_FACTOR % fmt.R
+    assert limbs(fmt.EMULATED_INV_NEG_SCALING_FACTOR) == pow(-fmt.SCALING_FACTOR, -1, fmt.R)
+    cc = compile_circuit(FormatCircuit(to_te))
+    vec = cc.assignment_vector(format_assignment(to_te))
+    w, *_ = cc.run_vprogram(vec)
+    assert cc.last_status == 0 and cc.is_satisfied(w)[0]
+    cc.run_vprogram(cc.assignment_vector(format_assignment(to_te, bad=True)))
+    assert cc.last_status != 0
+    rh = cref.R1csHandle(cc)
+    pk, vk, _ = groth16.setup(cc, 77, _mul)
+    ch = cref.CommitKeysHandle(pk)
+    rc, *_ = cref.r1cs_solve_ex(rh, ch, to_mont_array(vec))
+    assert rc == 0

@@ -13,7 +13,7 @@ from gnark_crypto_primitives_amd.frontend import compile_circuit
 from gnark_crypto_primitives_amd.hash import poseidon_native
 from gnark_crypto_primitives_amd.std import emulated as em
 from tests import helpers as H
-from tests.test_emulated import ArithCircuit
+from tests.test_emulated import ArithCircuit, FormatCircuit, format_assignment
 from tests.test_gpu_commitment import _check
 
 pytestmark = pytest.mark.gpu
@@ -58,3 +58,14 @@ def test_emulated_poseidon_matches_native(zk_ctx):
     assert sum(v << (64 * i) for i, v in enumerate(asg[0]["Expected"])) == poseidon_native.hash([1, 2, 3])
     _check(zk_ctx, cc, asg, [4], 81, wbits=(0, 0), publics=[list(a["Expected"]) for a in asg],
            max_batch=64)
+
+
+@pytest.mark.parametrize("to_te", [False, True], ids=["TEtoRTE", "RTEtoTE"])
+def test_format_native_and_emulated(zk_ctx, to_te):
+    """ecc/format/twistededwards_test.go:70-134 (both directions, native + emulated) proved on the GPU"""
+    cc = compile_circuit(FormatCircuit(to_te))
+    rng = random.Random(5)
+    asg = [format_assignment(to_te)] + \
+        [format_assignment(to_te, rng.randrange(H.R), rng.randrange(H.R)) for _ in range(66)]
+    asg[17] = format_assignment(to_te, 3, 4, bad=True)
+    _check(zk_ctx, cc, asg, [17], 90 + to_te)
