@@ -182,6 +182,35 @@ class Field:
         return _El([api.Select(sel, x, y) for x, y in zip(a.Limbs, b.Limbs)], self.params,
                    max(a.overflow, b.overflow), True)
 
+    def Lookup2(self, b0, b1, a, b, c, d):
+        """emulated.Field.Lookup2: a, b, c, d for (b1 b0) = 00, 01, 10, 11, limb by limb"""
+        els = [self._el(x) for x in (a, b, c, d)]
+        for e in els:
+            self._enforce_width(e)
+        api = self.api
+        return _El([api.Lookup2(b0, b1, *ls) for ls in zip(*(e.Limbs for e in els))], self.params,
+                   max(e.overflow for e in els), True)
+
+    def Mux(self, sel, *inputs):
+        """emulated.Field.Mux: inputs[sel], sel < len(inputs) (the reference passes 4 and 8 inputs,
+        tree/smt/emulated/utils.go:26,33): selector bits, then a tree of Selects per limb."""
+        els = [self._el(x) for x in inputs]
+        n = len(els)
+        if n == 1:
+            return els[0]
+        nbits = (n - 1).bit_length()
+        api = self.api
+        bits = api.ToBinary(sel, nbits)
+        if n != 1 << nbits:
+            api.AssertIsLessOrEqual(sel, n - 1)
+        level = els
+        for b in bits:
+            nxt = []
+            for i in range(0, len(level), 2):
+                nxt.append(self.Select(b, level[i + 1], level[i]) if i + 1 < len(level) else level[i])
+            level = nxt
+        return level[0]
+
     # ------------------------------------------------------------------ products
     @staticmethod
     def _limbs_for_hint(e):

@@ -119,8 +119,9 @@ def BytesFromString(s: str, fixed_len: int):
 
 # ---- utils/utils.go -------------------------------------------------------------------------------
 def PackScalarToVar(api, s):
-    """utils.PackScalarToVar (utils/utils.go:14-32) for an element that is already reduced: the
-    reference first calls ``field.Reduce``, which needs emulated arithmetic and is not restated."""
+    """utils.PackScalarToVar (utils/utils.go:14-32): ``field.Reduce`` (limb widths enforced; an
+    element with lazy additions behind it is reduced by a product check), then sum limb_i 2^(64 i)."""
+    s = _emulated.NewField(api, s.params).Reduce(s)
     acc = 0
     for i, limb in enumerate(s.Limbs):
         acc = api.Add(acc, api.Mul(limb, 1 << (s.params.bits_per_limb * i)))

@@ -129,6 +129,47 @@ def test_arithmetic_circuit_three_solvers(params):
     assert not verify.verify(vk, [pub[0] ^ 1] + pub[1:], proofs[0], coms[0], poks[0])
 
 
+def test_mux_lookup2_and_pack():
+    """Field.Mux / Lookup2 (tree/smt/emulated/utils.go:23-34 mux2 / mux3) and utils.PackScalarToVar
+    (utils/utils.go:14-32) on an element with lazy additions behind it"""
+    from gnark_crypto_primitives_amd import utils
+    params = em.BN254Fr
+    p = params.modulus
+
+    class C:
+        Packed = Public()
+        Sel = Secret()
+        A = Secret(4)
+        B = Secret(4)
+        Out = Secret(4)
+
+        def define(self, api):
+            f = em.NewField(api, params)
+            a, b = em.Element(self.A, params), em.Element(self.B, params)
+            z = f.Zero()
+            m = f.Mux(self.Sel, z, a, b, f.Add(a, b), a, f.Mul(a, b))     # six inputs
+            f.AssertIsEqual(m, em.Element(self.Out, params))
+            bits = api.ToBinary(self.Sel, 3)
+            l2 = f.Lookup2(bits[0], bits[1], z, a, b, f.Add(a, b))
+            api.AssertIsEqual(utils.PackScalarToVar(api, f.Add(l2, l2)), self.Packed)
+
+    cc = compile_circuit(C())
+    a, b = 0x1234567 << 200, p - 5
+    want = [0, a, b, (a + b) % p, a, a * b % p]
+    for sel in range(6):
+        asg = {"Packed": 2 * want[sel & 3] % p, "Sel": sel, "A": em.ValueOf(a, params),
+               "B": em.ValueOf(b, params), "Out": em.ValueOf(want[sel], params)}
+        w, *_ = cc.run_vprogram(cc.assignment_vector(asg))
+        assert cc.last_status == 0 and cc.is_satisfied(w)[0], sel
+        asg["Out"] = em.ValueOf(want[sel] + 1, params)
+        cc.run_vprogram(cc.assignment_vector(asg))
+        assert cc.last_status != 0
+    asg = {"Packed": 0, "Sel": 6, "A": em.ValueOf(a, params), "B": em.ValueOf(b, params),
+           "Out": em.ValueOf(0, params)}
+    cc.run_vprogram(cc.assignment_vector(asg))
+    assert cc.last_status != 0          # selector beyond the inputs
+
+
 def test_lazy_additions_force_reductions():
     """a long chain of additions and subtractions grows the overflow until Mul / Add must reduce"""
     params = em.BN254Fr
