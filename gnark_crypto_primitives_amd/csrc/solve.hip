@@ -367,32 +367,45 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
       default: {
         // class 0: the header quad names the class.  CLS_HIST: multiplicities of the table
         // 0 .. size - 1 among hdr.y queries (the hdr.z rows that follow, S queries per row) into
-        // the consecutive wires starting at slot q0.y: the sub-lanes zero the counters, then
-        // sub-lane 0 counts query by query (a read-modify-write per query: the counters stay field
-        // elements of the value file, a query outside the table counts nowhere).  CLS_COMMIT rows
-        // are never executed: the host ends a launch in front of them.
+        // the consecutive wires starting at slot q0.y.  The sub-lanes zero the counters, then every
+        // sub-lane walks its own column of the query rows and counts with an atomic add on the
+        // low word of the counter's slot (the sub-lanes of a proof share the counters; a query
+        // outside the table counts nowhere), then the sub-lanes turn the integers into field
+        // elements in place.  CLS_COMMIT rows are never executed: the host ends a launch in
+        // front of them.
         const uint4 hdr = prog[(size_t)r * (1 + S)];
         if ((hdr.x & 0xffu) == CLS_HIST && !(hdr.x & 0x100u)) {
           const uint4 q0 = prog[(size_t)r * (1 + S) + 1];
-          const uint32_t nq = __builtin_amdgcn_readfirstlane(hdr.y);
           const uint32_t nrows = __builtin_amdgcn_readfirstlane(hdr.z);
           const uint32_t size = __builtin_amdgcn_readfirstlane(hdr.w);
-          const Fr zero = Fr::zero(), one = f_one();
+          const Fr zero = Fr::zero();
           for (uint32_t j = sl; j < size; j += S) ST(q0.y + j, zero);
           __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-          if (sl == 0) {
-            const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1;
-            for (uint32_t t = 0; t < nq; t++) {
-              const uint4 p = pr[(size_t)(t / S) * (1 + S) + (t % S)];
-              if ((p.x & 0x1fu) != OP_HQ) continue;
-              const Fr v = f_plain(LD(p.z));
-              if ((v.v[1] | v.v[2] | v.v[3] | v.v[4] | v.v[5] | v.v[6] | v.v[7]) == 0 &&
-                  v.v[0] < size) {
-                ST(q0.y + v.v[0], add(LD(q0.y + v.v[0]), one));
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-              }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          const uint4* pr = prog + (size_t)(r + 1) * (1 + S) + 1 + sl;
+          for (uint32_t t = 0; t < nrows; t++) {
+            const uint4 p = pr[(size_t)t * (1 + S)];
+            if ((p.x & 0x1fu) != OP_HQ) continue;
+            const Fr v = f_plain(LD(p.z));
+            if ((v.v[1] | v.v[2] | v.v[3] | v.v[4] | v.v[5] | v.v[6] | v.v[7]) == 0 && v.v[0] < size) {
+              uint32_t* cnt = reinterpret_cast<uint32_t*>(
+                  reinterpret_cast<uint4*>(slots) + (size_t)(q0.y + v.v[0]) * 2 * Bp + lane);
+              __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          constexpr uint32_t c522h[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
+                                         0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};   // 2^522 mod r
+          Fr k522h;
+#pragma unroll
+          for (int t = 0; t < 8; t++) k522h.v[t] = c522h[t];
+          for (uint32_t j = sl; j < size; j += S) {
+            uint32_t* cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(slots) +
+                                                        (size_t)(q0.y + j) * 2 * Bp + lane);
+            Fr pm = Fr::zero();
+            pm.v[0] = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ST(q0.y + j, fmul(pm, k522h));
           }
           r += nrows;
           __builtin_amdgcn_s_waitcnt(0x0F70);
