@@ -876,7 +876,8 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
     return ZKMI_ERR_ARG;
   }
   // validate every slot / constant / row index on the host before anything reaches a kernel
-  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_EMUL = 11 };
+  enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_EMUL = 11,
+         CLS_LIMBS = 12 };
   enum { OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22, OP_BXOR = 23, OP_BAND = 24, OP_EMUL = 25 };
   std::vector<std::pair<uint32_t, uint32_t>> commit_rows;
   bool has_emul = false;
@@ -964,6 +965,25 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
       for (uint32_t l = 1; l < S; l++)
         if (h[4 * (1 + l)] != 0) return bad(r);
       commit_rows.emplace_back(r, q0[1]);
+      continue;
+    }
+    if (cls == CLS_LIMBS) {
+      // up to S short decompositions: quads (OP_BITS, first wire, source slot, count | width << 16)
+      // with class bits 0, idle quads all zero
+      bool any = false;
+      for (uint32_t l = 0; l < S; l++) {
+        const uint32_t* q = h + 4 * (1 + l);
+        if (q[0] == 0 && q[1] == 0 && q[2] == 0 && q[3] == 0) {
+          if (l == 0) return bad(r);   // the step's class is read from quad 0
+          continue;
+        }
+        const uint32_t n = q[3] & 0xffffu, wd = q[3] >> 16;
+        if (q[0] != OP_BITS || n == 0 || n > 16 || wd > 16 || q[2] >= d->n_slots ||
+            (uint64_t)q[1] + n > d->n_slots)
+          return bad(r);
+        any = true;
+      }
+      if (!any) return bad(r);
       continue;
     }
     if (cls < CLS_M || cls > CLS_BITS) return bad(r);

@@ -86,7 +86,7 @@ __device__ __forceinline__ Fr f_plain(const Fr& a) {  // x * 2^261 -> x as a pla
 // issue order (a workgroup-scope fence here -- s_waitcnt vmcnt(0) after every step -- exposed the
 // store latency: 96 -> 7x ms per batch).
 enum { CLS_M = 1, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B_UNUSED,
-       CLS_EMUL };
+       CLS_EMUL, CLS_LIMBS };
 // CLS_HIST / CLS_COMMIT do not fit the three class bits of an operand quad: their quads carry
 // class 0 and the class sits in the header quad.  OP_HIST = 20, OP_HQ = 21, OP_COMMIT = 22
 // (frontend/api.py).
@@ -409,6 +409,34 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
           }
           r += nrows;
           __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        // CLS_LIMBS: up to S short decompositions in one step (the limb hints of the range checker:
+        // a handful of limbs each; CLS_BITS splits ONE long decomposition over the sub-lanes instead).
+        // Every sub-lane's quad is (OP_BITS, first slot, source slot, count | width << 16), count <= 16.
+        if ((hdr.x & 0xffu) == CLS_LIMBS) {
+          if (op == OP_BITS) {
+            const uint32_t n = y & 0xffffu, wd = y >> 16;
+            const Fr v = f_plain(LD(x));
+            constexpr uint32_t c522l[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u,
+                                           0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};   // 2^522 mod r
+            Fr k522l;
+#pragma unroll
+            for (int t = 0; t < 8; t++) k522l.v[t] = c522l[t];
+            const uint32_t w1 = wd ? wd : 1u;
+            for (uint32_t i = 0; i < n; i++) {
+              const uint32_t pos = i * w1;
+              uint32_t m = 0;
+              if (pos < 256) {
+                const uint32_t lo = v.v[pos >> 5], hi = (pos >> 5) < 7 ? v.v[(pos >> 5) + 1] : 0u;
+                const uint64_t two = ((uint64_t)hi << 32) | lo;
+                m = (uint32_t)(two >> (pos & 31)) & ((1u << w1) - 1u);
+              }
+              Fr pm = Fr::zero();
+              pm.v[0] = m;
+              ST(d + i, fmul(pm, k522l));
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as after CLS_BITS
         }
         if constexpr (EMUL) {
           // CLS_EMUL: header (class, na + nb, n rows, aux), quad 0 = (OP_EMUL, first slot, 0, aux),

@@ -135,6 +135,8 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
             return (op | c << 6 | slot[ops[i][4]] << 9, slot[dst], slot[a], b)
         if op == OP_ABC:
             return (op | chk.get(i, 0) << 5 | c << 6 | row_of[i] << 9, slot[dst], slot[a], slot[b])
+        if c == sch.CLS_LIMBS:             # class bits 0: the kernel takes the class from the header
+            return (op, slot[dst], slot[a], b)
         w0 = op | c << 6 | (row_of[i] << 9 if i in row_of else 0)
         if op in (OP_BXOR, OP_BAND):       # scheduled as CLS_B, executed by the kernel's CLS_I arm
             return (op | sch.CLS_I << 6, slot[dst], slot[a], slot[b])
@@ -213,7 +215,8 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
         else:
             kc = sch.CLS_I if c == sch.CLS_B else c       # class the kernel sees
             quads = [quad(i, c) for i in idxs]
-            rows.append([(kc, len(idxs), 0, 0)] + quads + [(kc << 6, 0, 0, 0)] * (S - len(quads)))
+            idle = (0, 0, 0, 0) if c == sch.CLS_LIMBS else (kc << 6, 0, 0, 0)
+            rows.append([(kc, len(idxs), 0, 0)] + quads + [idle] * (S - len(quads)))
         # temporaries whose last reader is this step return to the pool for LATER steps
         for i in idxs:
             op, dst, a, b = ops[i][:4]

@@ -28,8 +28,12 @@ from .api import (OP_ABC, OP_ADD, OP_ADDC, OP_BAND, OP_BATCHINV, OP_BITS, OP_BXO
                   OP_SUB, OP_XOR, OP_XORABC)
 
 OP_FMAC, OP_FMA = 18, 19       # relin.py: (op, dst, x, const, addend) / (op, dst, x, y, addend)
-CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B, CLS_EMUL = \
-    range(1, 12)
+CLS_M, CLS_X, CLS_A, CLS_R, CLS_I, CLS_BITS, CLS_BINV, CLS_HIST, CLS_COMMIT, CLS_B, CLS_EMUL, \
+    CLS_LIMBS = range(1, 13)
+# CLS_LIMBS: OP_BITS with at most LIMBS_MAX outputs (the range checker's limb hints): S of them share
+# a step, one per sub-lane; a longer decomposition (ToBinary) is a CLS_BITS step of its own, its
+# outputs split over the sub-lanes
+LIMBS_MAX = 16
 # CLS_B (byte-op hints) is a scheduling class of its own -- a step never mixes them with inversions --
 # but runs in the kernel's CLS_I arm (its quads carry class CLS_I)
 # the class field of an operand quad has three bits: HIST / COMMIT rows carry 0 there and their
@@ -43,7 +47,13 @@ CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_
             OP_BAND: CLS_B, OP_EMUL: CLS_EMUL}
 # relative time of one step of the class on a lone wavefront (instruction counts / 40)
 COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000,
-        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20, CLS_EMUL: 1500}
+        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20, CLS_EMUL: 1500, CLS_LIMBS: 80}
+
+
+def class_of(o):
+    if o[0] == OP_BITS and (o[3] & 0xffff) <= LIMBS_MAX:
+        return CLS_LIMBS
+    return CLASS_OF[o[0]]
 
 
 def n_rows_of(o):
@@ -125,7 +135,7 @@ def schedule(ops, n_bits_vals, S):
                 seen.add(p)
                 succs[p].append(u)
                 npred[u] += 1
-    cls = {u: CLASS_OF[ops[u][0]] for u in units}
+    cls = {u: class_of(ops[u]) for u in units}
     # priority: longest weighted path to a sink
     prio = {}
     for u in reversed(units):
