@@ -871,8 +871,8 @@ int zkmi_cs_load(zkmi_ctx* ctx, const zkmi_cs_desc* d, zkmi_cs** out) {
   ZK_HIP(hipSetDevice(ctx->device));
   if (!d || !out) return ZKMI_ERR_ARG;
   const uint32_t S = d->lanes_per_proof;
-  if (S != 1 && S != 2 && S != 4 && S != 8 && S != 16) {
-    ctx->err = "cs: lanes_per_proof must be 1, 2, 4, 8 or 16";
+  if (S == 0 || S > 64 || (S & (S - 1))) {
+    ctx->err = "cs: lanes_per_proof must be a power of two, 1 .. 64";
     return ZKMI_ERR_ARG;
   }
   // validate every slot / constant / row index on the host before anything reaches a kernel

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64) void solve_vliw_kernel(const uint4* __restrict_
   // name the load -- which also waits for the previous step's STORES to be acknowledged before the
   // operand loads can even be issued: one L2 round trip per step on the critical path.  LDS reads
   // count on lgkmcnt, so the operand loads now follow the stores back to back.
-  constexpr uint32_t CH = 32, RQ = 1 + S, CQ = CH * RQ, NX = (CQ + 63) / 64;
+  // (fewer rows per chunk for 32 and 64 sub-lanes: the chunk stays ~520 quads, nine prefetch registers)
+  constexpr uint32_t CH = S > 32 ? 8 : S > 16 ? 16 : 32, RQ = 1 + S, CQ = CH * RQ, NX = (CQ + 63) / 64;
   __shared__ uint4 pq[CQ];
   const uint32_t total_q = n_rows * RQ;
   uint4 nx[NX];
@@ -605,8 +606,10 @@ int solve_rows(zkmi_ctx* ctx, const zkmi_cs* cs, Fr* slots, Fr* a, Fr* b, Fr* c,
     case 4: ZK_SOLVE(4); break;
     case 8: ZK_SOLVE(8); break;
     case 16: ZK_SOLVE(16); break;
+    case 32: ZK_SOLVE(32); break;
+    case 64: ZK_SOLVE(64); break;
     default:
-      ctx->err = "cs: lanes_per_proof must be 1, 2, 4, 8 or 16";
+      ctx->err = "cs: lanes_per_proof must be a power of two, 1 .. 64";
       return ZKMI_ERR_ARG;
   }
 #undef ZK_SOLVE

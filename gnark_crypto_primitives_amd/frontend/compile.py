@@ -69,7 +69,7 @@ def from_mont_array(a: np.ndarray):
     return [x * MONT_RINV % R for x in array_to_ints(a)]
 
 
-SUB_LANE_CHOICES = (1, 2, 4, 8, 16)
+SUB_LANE_CHOICES = (1, 2, 4, 8, 16, 32, 64)
 
 
 def emul_unit(limbs, aux, consts):
@@ -101,6 +101,9 @@ def build_vprogram(ops, val_wire, row_of, chk, n_wires, lanes_req=0):
     best = None
     # auto: 4 sub-lanes (idle sub-lanes cost nothing: the solve is a latency chain on an
     # otherwise empty SIMD), more only while doubling them shortens the schedule by >= 8 %
+    # (32 and 64 are accepted on request only: below four proofs per wavefront the value-file
+    # accesses stop filling their 64-byte lines and the steps get slower than they get fewer --
+    # measured)
     choices = (lanes_req,) if lanes_req else (4, 8, 16)
     for S in choices:
         if S not in SUB_LANE_CHOICES:
@@ -683,7 +686,7 @@ class CompiledCircuit:
 
 def compile_circuit(circuit, lanes_per_proof: int = 0, relinearize: bool = True) -> CompiledCircuit:
     """``frontend.Compile(field, r1cs.NewBuilder, circuit)`` for BN254's scalar field.
-    lanes_per_proof: sub-lanes of the GPU solver per proof (1, 2, 4, 8, 16; 0 = chosen from the
+    lanes_per_proof: sub-lanes of the GPU solver per proof (1, 2, 4, ... 64; 0 = chosen from the
     schedule lengths)."""
     api = API()
     fields = _fields(circuit)

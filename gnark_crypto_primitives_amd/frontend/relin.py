@@ -184,7 +184,7 @@ def relinearize(ops, val_wire, consts, n_vals):
             out.append((op, dst, a, b))
             out.extend((OP_HQ, 0, x, 0) for x in rows)
             d = max([dep(x) for x in rows], default=0) + \
-                (4000 if op == OP_HIST else 20000 if op == OP_COMMIT else 1500)
+                (4000 if op == OP_HIST else 20000 if op == OP_COMMIT else 150)
             for v in unit_outputs((op, dst, a, b)):
                 depth[v] = d
             continue

@@ -47,7 +47,7 @@ CLASS_OF = {OP_MUL: CLS_M, OP_MULC: CLS_M, OP_MULABC: CLS_M, OP_FMAC: CLS_M, OP_
             OP_BAND: CLS_B, OP_EMUL: CLS_EMUL}
 # relative time of one step of the class on a lone wavefront (instruction counts / 40)
 COST = {CLS_M: 10, CLS_X: 12, CLS_A: 2, CLS_R: 3, CLS_I: 4000, CLS_BITS: 40, CLS_BINV: 6000,
-        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20, CLS_EMUL: 1500, CLS_LIMBS: 80}
+        CLS_HIST: 4000, CLS_COMMIT: 20000, CLS_B: 20, CLS_EMUL: 150, CLS_LIMBS: 80}
 
 
 def class_of(o):

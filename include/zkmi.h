@@ -204,7 +204,7 @@ int zkmi_pk_info(const zkmi_pk* pk, uint64_t* info /* 10 */);
 typedef struct {
   uint32_t n_wires, n_public, n_secret, n_constraints;
   uint32_t n_slots, n_rows, n_consts;
-  uint32_t lanes_per_proof; /* 1, 2, 4, 8 or 16 */
+  uint32_t lanes_per_proof; /* a power of two, 1 .. 64 */
   const uint32_t* program;
   const void* consts;      /* n_consts fr elements, Montgomery */
 } zkmi_cs_desc;

@@ -179,7 +179,7 @@ def test_to_binary_254_rejects_the_unreduced_decomposition():
         assert (cc.last_status == 0) == good, x
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 0])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64, 0])
 def test_vliw_schedule_equals_the_sequential_program(lanes):
     """The scheduled program the GPU runs (vprogram: steps of up to S independent operations, slots
     recycled by step) computes the same wires, rows and status as the sequential program, on a
@@ -203,7 +203,7 @@ def test_vliw_schedule_equals_the_sequential_program(lanes):
     w["Root"] = (w["Root"] + 1) % R
     cases.append((cc2, cc2.assignment_vector(w), -5))
     for c, inp, want_status in cases:
-        assert c.lanes_per_proof in (1, 2, 4, 8, 16)
+        assert c.lanes_per_proof in (1, 2, 4, 8, 16, 32, 64)
         if lanes:
             assert c.lanes_per_proof == lanes
         seq = c.run_program(inp)

@@ -64,7 +64,7 @@ def _check(zk_ctx, cc, asg, bad, seed, wbits=(7, 5), publics=None, **plan):
         prover.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 4, 16])
+@pytest.mark.parametrize("lanes", [1, 4, 16, 64])
 def test_range_circuit(zk_ctx, lanes):
     cc = compile_circuit(RangeCircuit(), lanes)
     rng = random.Random(lanes)

@@ -19,8 +19,8 @@ from tests.test_gpu_commitment import _check
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("params,lanes", [(em.BN254Fr, 1), (em.BN254Fr, 4), (em.Secp256k1Fp, 2),
-                                          (em.Secp256k1Fp, 16), (em.BN254Fp, 8)],
+@pytest.mark.parametrize("params,lanes", [(em.BN254Fr, 1), (em.BN254Fr, 32), (em.Secp256k1Fp, 2),
+                                          (em.Secp256k1Fp, 64), (em.BN254Fp, 8)],
                          ids=lambda v: getattr(v, "name", str(v)))
 def test_emulated_arithmetic(zk_ctx, params, lanes):
     circ = ArithCircuit(params)

@@ -1,6 +1,6 @@
 """Parity holes named by the round-2 review:
 (a) every template instance of the witness solver -- solve_vliw_kernel<S>, S = lanes_per_proof in
-    {1, 2, 4, 8, 16} -- against the oracle's constraint-by-constraint solver (wires, a, b, c);
+    {1, 2, 4, 8, 16, 32, 64} -- against the oracle's constraint-by-constraint solver (wires, a, b, c);
 (b) BASELINE config 3 at full size: smt_verifier_circuit(160), inclusion + exclusion,
     isOld0 in {0, 1}, 1024 proofs under the auto plan, 64-lane oracle sample
     (tree/smt/verifier.go:66-81,102);
@@ -22,7 +22,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
 def test_solver_every_lane_count_vs_oracle(zk_ctx, lanes):
     from oracle import cref
     from tests.test_frontend import Mixed, _mixed_expected

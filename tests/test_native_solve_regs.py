@@ -34,6 +34,6 @@ def test_solver_kernels_keep_the_accumulation_registers_to_themselves():
     # S sub-lanes x {without, with} the OP_EMUL arm (std/math/emulated product hints)
     lanes = sorted((int(m.group(1)), int(m.group(2)))
                    for m in (re.search(r"kernelILi(\d+)ELb(\d)E", k) for k in seen))
-    assert lanes == [(s, e) for s in (1, 2, 4, 8, 16) for e in (0, 1)], lanes
+    assert lanes == [(s, e) for s in (1, 2, 4, 8, 16, 32, 64) for e in (0, 1)], lanes
     for name, r in seen.items():
         assert r == {"AGPRs": 32, "VGPRs Spill": 0}, (name, r)
