@@ -115,6 +115,7 @@ class API:
         self.println_log = []
         self.commitments = []       # {"private": [wires], "hashed": [wires], "wire": w}
         self._deferred = []
+        self._emul_moduli = {}      # modulus -> index of its first limb in the constant pool
 
     # ------------------------------------------------------------------ plumbing
     def _new_val(self):
@@ -633,14 +634,15 @@ class API:
         a_limbs = [self._v(x) for x in a_limbs]
         b_limbs = [self._v(x) for x in b_limbs]
         na, nb, nk, nr = len(a_limbs), len(b_limbs), int(n_quotient_limbs), EMUL_LIMBS
-        if not (1 <= na <= 4 and 1 <= nb <= 4 and 1 <= nk <= 8) or not 0 < modulus < 1 << 256:
-            raise CompileError("emulated product hint: 1..4 limbs per operand, 1..8 quotient limbs")
+        # 2^224 <= p: the solver's division normalises on the top 32-bit word of p (csrc/emul.h)
+        if not (1 <= na <= 4 and 1 <= nb <= 4 and 1 <= nk <= 8) or not 1 << 224 <= modulus < 1 << 256:
+            raise CompileError("emulated product hint: 1..4 limbs per operand, 1..8 quotient limbs, "
+                               "2^224 <= modulus < 2^256")
         p_limbs = [(modulus >> (64 * i)) & (2**64 - 1) for i in range(nr)]
         # the modulus' limbs sit in consecutive constants (appended together: _cid only shares)
-        cache = self.__dict__.setdefault("_emul_moduli", {})
-        first_c = cache.get(modulus)
+        first_c = self._emul_moduli.get(modulus)
         if first_c is None:
-            first_c = cache[modulus] = len(self.const_list)
+            first_c = self._emul_moduli[modulus] = len(self.const_list)
             for i, pl in enumerate(p_limbs):
                 self.const_list.append(pl)
                 self.consts.setdefault(pl, first_c + i)

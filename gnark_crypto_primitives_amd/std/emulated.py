@@ -77,8 +77,9 @@ class _El(Element):
 class Field:
     def __init__(self, api, params):
         from . import rangecheck
-        if params.nb_limbs != 4 or params.bits_per_limb != 64 or params.modulus >= 1 << 256:
-            raise ValueError("emulated.Field: 4 limbs of 64 bits")
+        if params.nb_limbs != 4 or params.bits_per_limb != 64 or \
+                not 1 << 224 <= params.modulus < 1 << 256:
+            raise ValueError("emulated.Field: 4 limbs of 64 bits, 2^224 <= modulus < 2^256")
         self.api, self.params, self.p = api, params, params.modulus
         self.rc = rangecheck.New(api)
         self.checks = []             # queued products: (a, b, r | None, k, c)
@@ -100,11 +101,9 @@ class Field:
         return self._one
 
     def Modulus(self):
-        return self._const_el_raw(self.p)
-
-    def _const_el_raw(self, v):
+        """emulated.Field.Modulus: p itself as an (unreduced) constant element"""
         m = (1 << 64) - 1
-        return _El([(v >> (64 * i)) & m for i in range(4)], self.params, 0, True, v)
+        return _El([(self.p >> (64 * i)) & m for i in range(4)], self.params, 0, True, 0)
 
     def NewElement(self, v):
         """int -> constant; Element (a witness' limbs) -> tracked element whose limb widths are
