@@ -170,6 +170,15 @@ class Field:
         return _El([api.Sub(api.Add(x, q), y) for x, q, y in zip(a.Limbs, pad, b.Limbs)],
                    self.params, max(a.overflow, b.overflow + 2) + 1, True)
 
+    def ModAdd(self, a, b, modulus):
+        """emulated.Field.ModAdd(a, b, modulus): (a + b) mod modulus for a modulus given as an
+        element.  The reference passes the field's own modulus (hash/emulated/bn254/mimc7/mimc.go:59):
+        the sum, reduced; any other modulus is not restated."""
+        m = self._el(modulus)
+        if m.const is None or sum(int(l) << (64 * i) for i, l in enumerate(m.Limbs)) != self.p:
+            raise NotImplementedError("ModAdd: only the field's own modulus")
+        return self.Reduce(self.Add(a, b))
+
     def Neg(self, a):
         return self.Sub(self._zero, a)
 

@@ -69,3 +69,37 @@ def test_format_native_and_emulated(zk_ctx, to_te):
         [format_assignment(to_te, rng.randrange(H.R), rng.randrange(H.R)) for _ in range(66)]
     asg[17] = format_assignment(to_te, 3, 4, bad=True)
     _check(zk_ctx, cc, asg, [17], 90 + to_te)
+
+
+def test_mimc7_native_and_emulated(zk_ctx):
+    """iden3 MiMC7 (hash/native/bn254/mimc7/mimc_test.go:18-49, hash/emulated/bn254/mimc7): the
+    reference's one-preimage circuits, native and over the emulated field, proved on the GPU and
+    compared with the C oracle's proofs"""
+    import numpy as np
+
+    from gnark_crypto_primitives_amd import groth16
+    from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+    from gnark_crypto_primitives_amd.hash import mimc7_native
+    from oracle import cref
+    from tests.test_mimc7 import EmulatedMiMCCircuit, _circuit
+    rng = random.Random(12)
+    cc = compile_circuit(_circuit(1))
+    xs = [12] + [rng.randrange(H.R) for _ in range(69)]
+    asg = [{"Hash": mimc7_native.hash([x]), "Preimages": [x]} for x in xs]
+    asg[33]["Hash"] = (asg[33]["Hash"] + 1) % H.R
+    pk, vk, _ = groth16.setup(cc, 3, groth16.gpu_mul(zk_ctx))
+    prover = groth16.Prover(zk_ctx, cc, pk, 7, 5)
+    inp = np.stack([to_mont_array(cc.assignment_vector(a)) for a in asg])
+    rs = np.stack([to_mont_array([rng.randrange(H.R), rng.randrange(H.R)]) for _ in asg])
+    proofs, status = prover.prove(inp, rs)
+    prover.close()
+    want, wstatus, _ = cref.groth16_prove_batch(cref.R1csHandle(cc), cref.PkHandle(pk), inp, rs)
+    assert set(np.nonzero(status)[0]) == {33} == set(np.nonzero(wstatus)[0])
+    ok = status == 0
+    assert np.array_equal(proofs[ok], want[ok])
+    # emulated: 364 product checks per proof
+    cc = compile_circuit(EmulatedMiMCCircuit(), 16)
+    mk = EmulatedMiMCCircuit.assignment
+    asg = [mk(12), mk(0), mk(H.R - 1), mk(rng.randrange(H.R)), mk(12, mimc7_native.hash([13]))]
+    _check(zk_ctx, cc, asg, [4], 13, wbits=(0, 0), publics=[list(a["Hash"]) for a in asg],
+           max_batch=64)
