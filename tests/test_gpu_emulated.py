@@ -103,3 +103,59 @@ def test_mimc7_native_and_emulated(zk_ctx):
     asg = [mk(12), mk(0), mk(H.R - 1), mk(rng.randrange(H.R)), mk(12, mimc7_native.hash([13]))]
     _check(zk_ctx, cc, asg, [4], 13, wbits=(0, 0), publics=[list(a["Hash"]) for a in asg],
            max_batch=64)
+
+
+def test_cs_load_refuses_malformed_unit_rows(zk_ctx):
+    """zkmi_cs_load checks every slot / constant / count of the unit rows on the host (OP_EMUL,
+    packed limb steps, OP_HIST) before a kernel can use them as addresses."""
+    import numpy as np
+
+    from gnark_crypto_primitives_amd import lib
+    from gnark_crypto_primitives_amd.frontend import schedule as sch
+    from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
+    cc = compile_circuit(ArithCircuit(em.BN254Fr), 4)
+    consts = to_mont_array(cc.consts)
+    S = cc.lanes_per_proof
+
+    def load(prog, n_consts=len(cc.consts), n_wires=cc.n_wires, n_slots=cc.v_n_slots):
+        prog = np.ascontiguousarray(prog, dtype=np.uint32)
+        cd = lib.CsDesc(n_wires, cc.n_public, cc.n_secret, cc.n_constraints, n_slots,
+                        prog.shape[0], n_consts, S, prog.ctypes.data, consts.ctypes.data)
+        h = zk_ctx.cs_load(cd)
+        zk_ctx.cs_free(h)
+
+    load(cc.vprogram)                                   # the real program loads
+    hdr = cc.vprogram[:, 0, 0]
+    emul = int(np.nonzero(hdr == sch.CLS_EMUL)[0][0])
+    limbs = int(np.nonzero(hdr == sch.CLS_LIMBS)[0][0])
+    hist = int(np.nonzero(hdr == sch.CLS_HIST)[0][0])
+
+    def broken(row, quad, word, value):
+        p = cc.vprogram.copy()
+        p[row, quad, word] = value
+        return p
+
+    aux = int(cc.vprogram[emul, 0, 3])
+    cases = [
+        broken(emul, 1, 1, cc.n_wires - 2),                       # outputs run past the wires
+        broken(emul, 0, 3, aux ^ 0x100),                          # header / quad disagree on aux
+        broken(emul + 1, 1, 2, cc.v_n_slots),                     # operand slot out of range
+        broken(emul, 0, 1, 9),                                    # operand count without its rows
+        broken(limbs, 1, 2, cc.v_n_slots),                        # source slot out of range
+        broken(limbs, 1, 3, 17 | 13 << 16),                       # more than 16 limbs in a packed step
+        broken(limbs, 1, 3, 4 | 17 << 16),                        # limb width above 16
+        broken(hist, 1, 1, cc.n_wires - 1),                       # counters run past the wires
+        broken(hist + 1, 1, 2, cc.v_n_slots),                     # query slot out of range
+    ]
+    for i, p in enumerate(cases):
+        with pytest.raises(lib.ZkmiError):
+            load(p)
+    p = cc.vprogram.copy()                                         # modulus constants past the pool
+    p[emul, 0, 3] = p[emul, 1, 3] = (aux & 0xfff) | (len(cc.consts) - 3) << 12
+    with pytest.raises(lib.ZkmiError):
+        load(p)
+    with pytest.raises(lib.ZkmiError):                            # sub-lane count not a power of two
+        prog = np.ascontiguousarray(cc.vprogram, dtype=np.uint32)
+        zk_ctx.cs_load(lib.CsDesc(cc.n_wires, cc.n_public, cc.n_secret, cc.n_constraints,
+                                  cc.v_n_slots, prog.shape[0], len(cc.consts), 12,
+                                  prog.ctypes.data, consts.ctypes.data))
