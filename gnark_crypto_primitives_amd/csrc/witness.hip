@@ -18,6 +18,10 @@
 #include <thread>
 
 #include "zkmi_internal.h"
+#include "ff29.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "ff29_asm.h"
+#endif
 
 using namespace zk;
 
@@ -26,7 +30,7 @@ struct zkmi_r1cs {
   uint32_t* ptr[3] = {};   // device, n_constraints + 1 offsets each (L, R, O)
   uint2* terms[3] = {};    // device, x = wire, y = coefficient index | kind << 30
   size_t nnz[3] = {};
-  Fr* coeffs = nullptr;    // device, gnark's Montgomery image
+  Fr* coeffs = nullptr;    // device, 2^261 images (gnark's Montgomery image times 2^5: fmul_261)
 };
 
 namespace zk {
@@ -187,6 +191,18 @@ struct R1csDev {
   const Fr* coeffs;
   uint32_t n_constraints;
 };
+// a b 2^-261 on the 9 x 29-bit form (the asm chain of ff29_asm.h, ~365 instructions against ~540 of
+// ff.h's mul): with the coefficients stored as 2^261 images (zkmi_r1cs_load lifts them by 2^5) a
+// wire in gnark's 2^256 image times a coefficient comes out in the 2^256 image again
+__device__ __forceinline__ Fr fmul_261(const Fr& a, const Fr& b) {
+  Fr r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  pack_canonical<Fr29Params>(r.v, mul_asm(unpack29<Fr29Params>(a.v), unpack29<Fr29Params>(b.v)));
+#else
+  r = a;   // device-only helper
+#endif
+  return r;
+}
 __global__ __launch_bounds__(256) void r1cs_eval_kernel(R1csDev m, const Fr* __restrict__ w,
                                                         Fr* __restrict__ a, Fr* __restrict__ b,
                                                         Fr* __restrict__ c, int32_t* __restrict__ st,
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) void r1cs_eval_kernel(R1csDev m, const Fr* __r
       else if (kind == 2)
         sum = sub(sum, x);
       else
-        sum = add(sum, mul(x, m.coeffs[tm.y & 0x3fffffffu]));
+        sum = add(sum, fmul_261(x, m.coeffs[tm.y & 0x3fffffffu]));
     }
     acc[s] = sum;
   }
@@ -339,6 +355,8 @@ int zkmi_r1cs_load(zkmi_ctx* ctx, const zkmi_r1cs_desc* d, zkmi_r1cs** out) {
       return ZKMI_ERR_HIP;
     }
   }
+  for (Fr& x : coeffs)   // 2^256 image -> 2^261 image, what r1cs_eval_kernel's products expect
+    for (int t = 0; t < 5; t++) x = add(x, x);
   if (hipMalloc((void**)&m->coeffs, (size_t)d->n_coeffs * 32) != hipSuccess ||
       hipMemcpy(m->coeffs, coeffs.data(), (size_t)d->n_coeffs * 32, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipGetLastError();
