@@ -19,8 +19,7 @@ from tests.test_gpu_commitment import _check
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("params,lanes", [(em.BN254Fr, 1), (em.BN254Fr, 32), (em.Secp256k1Fp, 2),
-                                          (em.Secp256k1Fp, 64), (em.BN254Fp, 8)],
+@pytest.mark.parametrize("params,lanes", [(em.BN254Fr, 1), (em.Secp256k1Fp, 64), (em.BN254Fp, 8)],
                          ids=lambda v: getattr(v, "name", str(v)))
 def test_emulated_arithmetic(zk_ctx, params, lanes):
     circ = ArithCircuit(params)
@@ -71,17 +70,18 @@ def test_format_native_and_emulated(zk_ctx, to_te):
     _check(zk_ctx, cc, asg, [17], 90 + to_te)
 
 
-def test_mimc7_native_and_emulated(zk_ctx):
-    """iden3 MiMC7 (hash/native/bn254/mimc7/mimc_test.go:18-49, hash/emulated/bn254/mimc7): the
-    reference's one-preimage circuits, native and over the emulated field, proved on the GPU and
-    compared with the C oracle's proofs"""
+def test_mimc7_native(zk_ctx):
+    """iden3 MiMC7 (hash/native/bn254/mimc7/mimc_test.go:18-49): the reference's one-preimage circuit
+    proved on the GPU and compared with the C oracle's proofs (the emulated variant runs through
+    the interpreters in tests/test_mimc7.py; the emulated machinery on the GPU is the Poseidon test
+    above)"""
     import numpy as np
 
     from gnark_crypto_primitives_amd import groth16
     from gnark_crypto_primitives_amd.frontend.compile import to_mont_array
     from gnark_crypto_primitives_amd.hash import mimc7_native
     from oracle import cref
-    from tests.test_mimc7 import EmulatedMiMCCircuit, _circuit
+    from tests.test_mimc7 import _circuit
     rng = random.Random(12)
     cc = compile_circuit(_circuit(1))
     xs = [12] + [rng.randrange(H.R) for _ in range(69)]
@@ -97,12 +97,6 @@ def test_mimc7_native_and_emulated(zk_ctx):
     assert set(np.nonzero(status)[0]) == {33} == set(np.nonzero(wstatus)[0])
     ok = status == 0
     assert np.array_equal(proofs[ok], want[ok])
-    # emulated: 364 product checks per proof
-    cc = compile_circuit(EmulatedMiMCCircuit(), 16)
-    mk = EmulatedMiMCCircuit.assignment
-    asg = [mk(12), mk(0), mk(H.R - 1), mk(rng.randrange(H.R)), mk(12, mimc7_native.hash([13]))]
-    _check(zk_ctx, cc, asg, [4], 13, wbits=(0, 0), publics=[list(a["Hash"]) for a in asg],
-           max_batch=64)
 
 
 def test_cs_load_refuses_malformed_unit_rows(zk_ctx):
