@@ -15,9 +15,9 @@ ScalarField = emulated.BN254Fr      # sw_bn254.ScalarField
 
 
 class Poseidon:
-    def __init__(self, api):
+    def __init__(self, api, field=None):
         self.api = api
-        self.field = emulated.NewField(api, ScalarField)
+        self.field = field if field is not None else emulated.NewField(api, ScalarField)
         self.data = []
 
     def Write(self, *data):
