@@ -107,7 +107,11 @@ def cached(name, make, load, save, use_cache=True):
             return load(path), True
         except Exception:
             pass
-    with open(path + ".lock", "w") as lk:
+    try:
+        lk = open(path + ".lock", "w")
+    except OSError:
+        return make(), False
+    with lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         if os.path.exists(path):
             try:
@@ -116,8 +120,14 @@ def cached(name, make, load, save, use_cache=True):
                 pass
         obj = make()
         tmp = f"{path}.{os.getpid()}.tmp"
-        save(tmp, obj)
-        os.replace(tmp, path)
+        try:                          # a full or read-only cache directory only costs the cache
+            save(tmp, obj)
+            os.replace(tmp, path)
+        except OSError:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
         return obj, False
 
 
