@@ -781,7 +781,9 @@ WinPlan plan_comb(int k, bool signed_tables) {
 // per group and need 255 windows, subset-sum tables 2^k entries and 254 windows.  Relative cost of
 // one mixed addition, measured on MI355X (Arbo-160 key, ns per (group, window) at 1024 proofs):
 // G1 subset-sum 61.1, G1 sign-pattern 62.8 (the per-lane negation), G2 subset-sum 171.6, G2
-// sign-pattern 198.8 (the 256-register G2 kernel spills more with the extra live sign).
+// sign-pattern 178.5 (198.8 while the G2 accumulator's zz / zzz lived in scratch: the extra live sign
+// spilled; re-measured with them in LDS at the end of round 3: 60.5 ms against 58.0 ms per MSM at
+// k = 19, and 57.1 ms with the k = 20 the same HBM affords).
 void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, int* k2, bool* sg1,
                           bool* sg2, bool allow_signed) {
   // allow_signed = false: witnesses of bits / small integers (zkmi_pk_desc.sparse_witness): only
@@ -797,7 +799,7 @@ void plan_comb_for_budget(size_t n1, size_t n2, double usable_bytes, int* k1, in
           const double g1 = (double)((n1 + a - 1) / a), g2 = (double)((n2 + b - 1) / b);
           const double bytes = g1 * (double)(1u << (a - s1)) * 64.0 + g2 * (double)(1u << (b - s2)) * 128.0;
           if (bytes > usable_bytes) continue;
-          const double cost = g1 * (s1 ? 255 * 62.8 : 254 * 61.1) + g2 * (s2 ? 255 * 198.8 : 254 * 171.6);
+          const double cost = g1 * (s1 ? 255 * 62.8 : 254 * 61.1) + g2 * (s2 ? 255 * 178.5 : 254 * 171.6);
           if (cost < best) {
             best = cost;
             *k1 = a;
