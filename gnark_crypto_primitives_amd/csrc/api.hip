@@ -834,6 +834,7 @@ int zkmi_pk_load(zkmi_ctx* ctx, const zkmi_pk_desc* d, zkmi_pk** out) {
       zkmi_pk_free(ctx, pk);
       return rc;
     }
+    pk->D1->side = pk->D2->side = 2;   // run on the assembly stream (enqueue_heavy)
   }
   hipMemcpy(&pk->alpha, d->g1_alpha, 64, hipMemcpyDefault);
   hipMemcpy(&pk->beta1, d->g1_beta, 64, hipMemcpyDefault);
@@ -1334,12 +1335,22 @@ static int enqueue_heavy(zkmi_ctx* ctx, int si) {
   ctx->msm_ev_set = -1;
   if (rc) return rc;
   hipEventRecord(S.evq[3], ctx->stream);
-  hipLaunchKernelGGL(rs_prep_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, ctx->stream, rs_bi, Bp);
-  if ((rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 0, Bp, v.tR)) ||
-      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 1, Bp, v.tS)) ||
-      (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, v.tNRS)) ||
-      (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, v.tS2)))
-    return rc;
+  // The multiples of delta (r, s, -rs times delta1; s times delta2) are four one-base MSMs of sixteen
+  // wavefronts each: latency, not work.  They run on the assembly stream, which is where their
+  // results are used, with their own partial-sum scratch (side = 2) -- on the main stream they were
+  // 4.2 ms per batch during which 240 CUs idled.
+  {
+    hipStream_t main_stream = ctx->stream;
+    ZK_HIP(hipStreamWaitEvent(q3, S.ev1, 0));   // r, s staged by the submit
+    ctx->stream = q3;
+    hipLaunchKernelGGL(rs_prep_kernel, dim3((unsigned)(Bp / 64)), dim3(64), 0, q3, rs_bi, Bp);
+    (void)((rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 0, Bp, v.tR)) ||
+           (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 1, Bp, v.tS)) ||
+           (rc = msm_run(ctx, pk->D1, rs_bi, pk->idx3 + 2, Bp, v.tNRS)) ||
+           (rc = msm_run(ctx, pk->D2, rs_bi, pk->idx3 + 1, Bp, v.tS2)));
+    ctx->stream = main_stream;
+    if (rc) return rc;
+  }
   if ((rc = commit_pok(ctx, S))) return rc;   // commitment extension: proof of knowledge
   hipEventRecord(S.evq[4], ctx->stream);
   S.heavy_enqueued = true;

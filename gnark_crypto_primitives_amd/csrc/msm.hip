@@ -1187,9 +1187,11 @@ int run_impl(zkmi_ctx* ctx, const zkmi_msm_bases* bases, const Fr* scalars,
   chunks = (n + per_chunk - 1) / per_chunk;
   void* partial;
   // partials + room for the intermediate level of the reduction
-  // side bases (commitment MSMs on the second stream) own scratch slot 18: the main stream may be
-  // running an MSM of the previous batch on slot 6 at the same time
-  int rc = ensure_scratch(ctx, bases->side ? 18 : 6, (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
+  // side bases own their scratch slot -- 18: commitment MSMs on the second stream, 21: the delta
+  // multiples on the assembly stream --: the main stream may be running an MSM on slot 6 at the
+  // same time
+  int rc = ensure_scratch(ctx, bases->side == 2 ? 21 : bases->side ? 18 : 6,
+                          (chunks + 256) * Bp * sizeof(XYZZ<F>), &partial);
   if (rc) return rc;
   if (!bases->side && ctx->part_ev_valid[0]) {   // a deferred tail of an earlier MSM may still be reading this buffer
     ZK_HIP(hipStreamWaitEvent(ctx->stream, ctx->part_ev[0], 0));

@@ -138,7 +138,8 @@ struct zkmi_msm_bases {
   zk::G1Affine stotal1 = {};   // signed comb tables: sum of all bases (G1 / G2 by `group`)
   zk::G2Affine stotal2 = {};
   // side = 1: per-window plan run on the second stream (commitment MSMs of a submit, beside the
-  // previous batch's MSMs on the main stream): its own partial-sum scratch, no deferred tails
+  // previous batch's MSMs on the main stream): its own partial-sum scratch, no deferred tails.
+  // side = 2: the same for the one-base tables of delta, run on the assembly stream
   int side = 0;
 };
 
